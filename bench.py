@@ -1,0 +1,162 @@
+#!/usr/bin/env python3
+"""Benchmark of the ray-tracing hot path on MI355X.
+
+Default workload (BASELINE.json configs[1]): a ~1.31 M-triangle fractal-displaced icosphere,
+1920x1080 primary rays (one per pixel), closest-hit traversal on one GPU.  A step is one pass
+of the closest-hit kernel over the whole frame's rays, which are resident in HBM before the
+timed region starts.  With N > 1 ranks (torch.distributed, one process per GPU) every rank
+traces its own full frame of jittered primary rays (weak scaling, no data-path collective) and
+the reported value is the total over ranks divided by the slowest rank's time.
+
+Prints one JSON line (rank 0).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--subdiv", type=int, default=8, help="icosphere subdivisions (8 -> 1 310 720 triangles)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    from raytracer_amd import abi, api, scenes
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback for the ray-tracing path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+    api.set_device(local_rank)
+
+    W, H = args.width, args.height
+    sc, cam_m, yfov = scenes.blob_scene(args.subdiv)
+    ntri = sc.n_triangles()
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    scene = api.Scene(sc)
+    info = scene.info()
+
+    n = W * H
+    # rank 0 traces pixel-centre rays, other ranks jittered ones (different sample of the same frame)
+    st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, seed=rank,
+                           jitter_mode=abi.JITTER_CENTER if rank == 0 else abi.JITTER_RANDOM)
+    d_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_hits = torch.empty((n, 5), dtype=torch.int32, device=dev)  # rtgpu_hit = 5 dwords
+    stream = torch.cuda.current_stream()
+    api.generate_primary_device(cam, st, 0, d_o, d_d, stream)
+    torch.cuda.synchronize()
+
+    # per-ray work counters of the kernel's own traversal (for the algorithmic byte count)
+    d_cnt = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    scene.trace_counts_device(d_o, d_d, n, d_cnt, stream)
+    torch.cuda.synchronize()
+    cnt = d_cnt.to(torch.float64).mean(dim=0).tolist()
+    n_nodes, n_tris = cnt[0], cnt[1]
+
+    for _ in range(args.warmup):
+        scene.trace_rays_device(d_o, d_d, n, d_hits, stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    t0 = time.perf_counter()
+    ev[0].record(stream)
+    for k in range(args.steps):
+        scene.trace_rays_device(d_o, d_d, n, d_hits, stream)
+        ev[k + 1].record(stream)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    elapsed = t1 - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kernel_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
+    kernel_ms_avg = float(np.mean(kernel_ms))
+    hits = d_hits.cpu().numpy().view(np.uint32)
+    hit_frac = float((hits[:, 2] != 0xFFFFFFFF).mean())
+
+    total_rays = float(n) * args.steps * world
+    mrays = total_rays / elapsed / 1e6
+    # algorithmic bytes per ray: ray in 32 B, hit out 16 B, 32 B per tree-node box record and
+    # 36 B per triangle tested (per-ray averages counted by the kernel's own traversal)
+    bytes_per_ray = 32.0 + 16.0 + 32.0 * n_nodes + 36.0 * n_tris
+    achieved = bytes_per_ray * n / (kernel_ms_avg * 1e-3) / 1e9
+    traffic = None
+    tpath = os.path.join(HERE, "profiles", "traffic_trace_closest.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    out = {
+        "metric": "Mrays/s (primary+secondary) and ms/frame at fixed spp, 1/2/4/8 MI355X",
+        "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "configs[1]: fractal-displaced icosphere, %d triangles, %dx%d primary rays (1 per pixel), "
+                               "closest hit on one MI355X per rank" % (ntri, W, H),
+                   "rays_per_step_per_gpu": n, "hit_fraction": hit_frac, "tree_nodes": int(info.n_nodes),
+                   "tree_max_depth": int(info.max_depth), "scene_build_ms": float(info.build_ms),
+                   "scene_hbm_bytes": int(info.device_bytes)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                     "kernel": "trace_closest_kernel", "kernel_ms_avg": kernel_ms_avg,
+                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris},
+    }
+
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import oracle
+        threads = oracle.default_threads()
+        t0 = time.perf_counter()
+        osc = oracle.OracleScene(sc, threads=threads)
+        build_s = time.perf_counter() - t0
+        o_h = d_o.cpu().numpy()
+        d_h = d_d.cpu().numpy()
+        reps, spent = 0, 0.0
+        while spent < 10.0 and reps < 50:
+            t0 = time.perf_counter()
+            ref = osc.trace_closest(o_h, d_h, threads=threads)
+            spent += time.perf_counter() - t0
+            reps += 1
+        same = (ref["inst"] == hits[:, 2]) & (ref["prim"] == hits[:, 1])
+        out["cpu_baseline"] = {"value": n * reps / spent / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                               "sample": "the same %d primary rays, %d passes of the CPU oracle (%.1f s), tree build %.1f s excluded"
+                                         % (n, reps, spent, build_s),
+                               "id_mismatches_vs_gpu": int((~same).sum())}
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,249 @@
+/*
+ * rtgpu.h -- C ABI of the MI355X (gfx950) ray-tracing hot path.
+ *
+ * This is the drop-in boundary for the data-parallel hot path of Wouterdek/raytracer:
+ * spatial-tree traversal, ray/triangle and ray/sphere intersection and the path-tracing
+ * integrator.  The reference has no FFI layer on this path (it is one C++ process); the
+ * two C++ seams this ABI replaces are
+ *
+ *   (1) Renderer::render(scene, FrameBuffer&, perfBuffer, Tile, RenderSettings, ProgressMonitor, bool)
+ *       raytracer/src/lib/renderer/Renderer.h:17        -> rtgpu_render / rtgpu_render_device
+ *   (2) Scene::traceRay / Scene::traceRays / Scene::testVisibility
+ *       raytracer/src/lib/scene/renderable/Scene.h:96-100 -> rtgpu_trace_closest / rtgpu_trace_any
+ *
+ * and the scene hand-over replaces DynamicScene::build()
+ *   raytracer/src/lib/scene/dynamic/DynamicScene.cpp:99-161 -> rtgpu_scene_create.
+ *
+ * Conventions: plain pointers and sizes, no exceptions cross the ABI, every function
+ * returns an rtgpu_status and rtgpu_last_error() holds the message of the last failure on
+ * the calling thread.  All calls block until the result is complete unless the name ends
+ * in _device (those enqueue on the given HIP stream and return; the caller synchronises).
+ * One host thread per scene handle at a time.
+ */
+#ifndef RTGPU_H
+#define RTGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RTGPU_INVALID_ID 0xFFFFFFFFu /* RayHitInfo::triangleIndex of analytic shapes, math/RayHitInfo.h:22-24 */
+#define RTGPU_SHAPE_SPHERE (-1)       /* unit sphere at the object-space origin, shape/Sphere.cpp:16-59 */
+
+typedef enum rtgpu_status {
+    RTGPU_OK = 0,
+    RTGPU_ERR_INVALID_ARGUMENT = 1, /* std::invalid_argument in the reference (film/Tile.cpp:11, film/FrameBuffer.cpp:9-14) */
+    RTGPU_ERR_NO_DEVICE = 2,        /* no gfx950 device / HIP runtime unusable */
+    RTGPU_ERR_HIP = 3,              /* a HIP call failed; message holds hipGetErrorString */
+    RTGPU_ERR_OUT_OF_MEMORY = 4,
+    RTGPU_ERR_NO_CAMERA = 5,        /* std::runtime_error("No camera in scene.") renderer/Renderer.cpp:318 */
+    RTGPU_ERR_LIMIT = 6             /* a documented size limit of an entry point was exceeded */
+} rtgpu_status;
+
+/* ---- scene description (flat arrays; replaces the DynamicScene graph) ---------------- */
+
+/* TriangleMeshData, shape/TriangleMesh.h:8-21.  Normals are per vertex and share the vertex
+ * indices (what io/GLTF.cpp produces).  tri_material, when non-NULL, is the flattened
+ * CompositeMaterial range table (material/CompositeMaterial.cpp:41-84): one material id per
+ * triangle in the caller's (original) triangle order. */
+typedef struct rtgpu_mesh_desc {
+    const float* vertices;        /* n_vertices * 3 */
+    const float* normals;         /* n_vertices * 3 */
+    const uint32_t* indices;      /* n_triangles * 3 */
+    const uint32_t* tri_material; /* n_triangles or NULL */
+    uint32_t n_vertices;
+    uint32_t n_triangles;
+} rtgpu_mesh_desc;
+
+/* SceneNode<Model>: transform + (shape, material), scene/renderable/SceneNode.h:5-36,
+ * model/Model.h:9-47.  Matrices are row-major 4x4 doubles like Transformation's Matrix4d
+ * pair (math/Transformation.h:40-43); the caller supplies the inverse, as the reference does. */
+typedef struct rtgpu_instance_desc {
+    int32_t shape;     /* index into meshes[], or RTGPU_SHAPE_SPHERE */
+    uint32_t material; /* material id (ignored for triangles of a mesh with tri_material) */
+    double transform[16];
+    double inverse[16];
+} rtgpu_instance_desc;
+
+typedef enum rtgpu_material_type {
+    RTGPU_MAT_DIFFUSE = 0,  /* material/DiffuseMaterial.cpp */
+    RTGPU_MAT_GLOSSY = 1,   /* material/GlossyMaterial.cpp  ("specular") */
+    RTGPU_MAT_EMISSIVE = 2, /* material/EmissiveMaterial.cpp */
+    RTGPU_MAT_CONSTMIX = 3  /* material/MixMaterial.h:19-26 */
+} rtgpu_material_type;
+
+typedef struct rtgpu_material {
+    int32_t type;       /* rtgpu_material_type */
+    float color[3];     /* diffuseColor / color */
+    double intensity;   /* diffuseIntensity / emissive intensity */
+    float roughness;    /* glossy */
+    float reserved;
+    double mix_factor;  /* const mix: 0 = 100 % first, 1 = 100 % second */
+    uint32_t first;     /* const mix children (material ids) */
+    uint32_t second;
+} rtgpu_material;
+
+typedef struct rtgpu_point_light { /* light/PointLight.h:9-22 (world space) */
+    float pos[3];
+    float color[3];
+    double intensity;
+} rtgpu_point_light;
+
+typedef struct rtgpu_area_light { /* light/AreaLight.h (one world-space triangle) */
+    float a[3];
+    float b[3];
+    float c[3];
+    float color[3];
+    double intensity;
+} rtgpu_area_light;
+
+typedef struct rtgpu_scene_desc {
+    const rtgpu_mesh_desc* meshes;
+    const rtgpu_instance_desc* instances;
+    const rtgpu_material* materials;
+    const rtgpu_point_light* point_lights;
+    const rtgpu_area_light* area_lights;
+    uint32_t n_meshes;
+    uint32_t n_instances;
+    uint32_t n_materials;
+    uint32_t n_point_lights;
+    uint32_t n_area_lights;
+    int32_t has_environment; /* ColorEnvironment, material/environment/ColorEnvironment.cpp:6-9 */
+    float env_color[3];
+    double env_intensity;
+} rtgpu_scene_desc;
+
+typedef struct rtgpu_scene rtgpu_scene;
+
+/* ---- query results ------------------------------------------------------------------- */
+
+/* The part of SceneRayHitInfo (scene/renderable/SceneRayHitInfo.h:9-21, math/RayHitInfo.h:13-59)
+ * that identifies a hit.  prim is the triangle's index in the caller's order (the reference's
+ * permutation[triangleIndex]), RTGPU_INVALID_ID for a sphere; inst is the index into
+ * instances[]; a miss has inst == prim == RTGPU_INVALID_ID and t == +inf. */
+typedef struct rtgpu_hit {
+    float t;
+    uint32_t prim;
+    uint32_t inst;
+    float beta;
+    float gamma;
+} rtgpu_hit;
+
+/* ---- camera and render settings ------------------------------------------------------ */
+
+/* The state of PerspectiveCamera (camera/PerspectiveCamera.h:22-24; private there, so the
+ * host owns this POD).  u,v,w = OrthonormalBasis of the camera; width = 2 tan(fov_x / 2). */
+typedef struct rtgpu_camera {
+    float origin[3];
+    float u[3];
+    float v[3];
+    float w[3];
+    double width;
+    double aperture;       /* 0 = pinhole */
+    double focal_distance;
+} rtgpu_camera;
+
+typedef enum rtgpu_jitter_mode {
+    RTGPU_JITTER_RANDOM = 0, /* sampleUniformStratifiedSquare as the reference draws it (math/Sampler.h:13-26) */
+    RTGPU_JITTER_CENTER = 1  /* deterministic centre of the stratum (pixel centre when geometry_aa < 4) */
+} rtgpu_jitter_mode;
+
+/* RenderSettings (renderer/Renderer.h:8-12) + the Tile (film/Tile.h) + FrameBuffer size. */
+typedef struct rtgpu_render_settings {
+    int32_t width, height;                       /* FrameBuffer resolution */
+    int32_t x_start, y_start, x_end, y_end;      /* half-open tile, film/Tile.h:19-23 */
+    int32_t geometry_aa;                         /* geometryAAModifier (default 4) */
+    int32_t material_aa;                         /* materialAAModifier (default 32) */
+    int32_t max_path_length;                     /* reference hard-codes 10, renderer/Renderer.cpp:130 */
+    uint32_t seed;                               /* key of the counter-based RNG */
+    int32_t jitter_mode;                         /* rtgpu_jitter_mode */
+    int32_t reserved;
+} rtgpu_render_settings;
+
+typedef struct rtgpu_render_stats {
+    uint64_t primary_rays;   /* Scene::traceRay calls from renderer/Renderer.cpp:161,170 */
+    uint64_t extension_rays; /* renderer/Renderer.cpp:60, material/GlossyMaterial.cpp:124 */
+    uint64_t shadow_rays;    /* material/NextEventEstimation.cpp:16,38 */
+    double device_ms;        /* HIP-event time of the whole call on the device */
+} rtgpu_render_stats;
+
+/* ProgressMonitor, utility/ProgressMonitor.h:8 (job name, fraction done, finished flag). */
+typedef void (*rtgpu_progress_cb)(const char* job, float fraction, int finished, void* user);
+
+/* ---- entry points -------------------------------------------------------------------- */
+
+const char* rtgpu_last_error(void);
+
+/* Number of usable gfx950 devices (0 if none; never fails). */
+int rtgpu_device_count(void);
+
+/* Select the HIP device later calls on this thread use (default 0). */
+int rtgpu_set_device(int device);
+
+/* Replaces DynamicScene::build (scene/dynamic/DynamicScene.cpp:99-161): builds the
+ * per-mesh and top-level SAH trees on the host (shape/bvh/BVHBuilder.h:144-361), flattens
+ * them (shape/bvh/BVH.h:70-113) and uploads nodes, triangles, instances, materials and
+ * lights to the current device. */
+int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene);
+void rtgpu_scene_destroy(rtgpu_scene* scene);
+
+/* Scene::traceRay over a batch (scene/renderable/Scene.cpp:14-17).  origins/dirs: n*3 floats. */
+int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const float* dirs,
+                        uint64_t n, rtgpu_hit* out_hits);
+/* Same with device-resident buffers, enqueued on hip_stream (a hipStream_t, NULL = default). */
+int rtgpu_trace_closest_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                               uint64_t n, rtgpu_hit* d_out_hits, void* hip_stream);
+
+/* Scene::testVisibility over a batch (scene/renderable/Scene.cpp:19-22): occluded[i] = 1 when
+ * something is hit with t <= tmax[i]. */
+int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float* dirs,
+                    const float* tmax, uint64_t n, uint8_t* out_occluded);
+int rtgpu_trace_any_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                           const float* d_tmax, uint64_t n, uint8_t* d_out_occluded, void* hip_stream);
+
+/* PerspectiveCamera::generateRay for every pixel of the tile and one sample index
+ * (camera/PerspectiveCamera.cpp:26-52).  Writes (x_end-x_start)*(y_end-y_start) rays,
+ * row-major inside the tile, into device buffers of 3 floats per ray. */
+int rtgpu_generate_primary_device(const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                                  int32_t sample_index, float* d_origins, float* d_dirs, void* hip_stream);
+
+/* Renderer::render (renderer/Renderer.cpp:273-299).  rgb_out is the whole FrameBuffer
+ * (width*height*3 floats, pixel (x,y) at (y*width+x)*3, film/FrameBuffer.h:14-22); only pixels
+ * inside the tile are written.  stats and progress may be NULL. */
+int rtgpu_render(const rtgpu_scene* scene, const rtgpu_camera* camera,
+                 const rtgpu_render_settings* settings, float* rgb_out,
+                 rtgpu_render_stats* stats, rtgpu_progress_cb progress, void* user);
+/* Same, writing into a device-resident framebuffer on hip_stream; returns after the work is
+ * complete (the integrator loop needs host-side queue sizes). */
+int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera,
+                        const rtgpu_render_settings* settings, float* d_rgb_out,
+                        rtgpu_render_stats* stats, void* hip_stream);
+
+/* PerspectiveCamera(fov) + setTransform (camera/PerspectiveCamera.cpp:7-19): fills *out from a
+ * horizontal field of view in degrees and a row-major object->world 4x4. */
+int rtgpu_camera_from_transform(double fov_x_degrees, const double transform[16], rtgpu_camera* out);
+
+/* Tree statistics of a built scene (LOGSTAT keys of shape/bvh/BVHBuilder.h:329-337). */
+typedef struct rtgpu_scene_info {
+    uint64_t n_triangles;     /* over all meshes */
+    uint64_t n_nodes;         /* flattened inner nodes over all trees */
+    uint64_t n_leaves;
+    uint32_t max_depth;
+    uint32_t max_leaf_size;
+    uint64_t device_bytes;    /* HBM held by the scene */
+    double build_ms;
+} rtgpu_scene_info;
+int rtgpu_scene_get_info(const rtgpu_scene* scene, rtgpu_scene_info* out);
+
+/* Per-ray traversal work counters of the closest-hit kernel, for the roofline model:
+ * d_counts receives 2 uint32 per ray {node records fetched, triangles tested}. */
+int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                                     uint64_t n, uint32_t* d_counts, void* hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RTGPU_H */

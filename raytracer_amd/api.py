@@ -1,0 +1,207 @@
+"""Host-side mirror of the reference's query/render interface on top of the C ABI (librtgpu.so).
+
+`Scene.trace_ray(s)` / `Scene.test_visibility` mirror Scene::traceRay / Scene::testVisibility
+(raytracer/src/lib/scene/renderable/Scene.h:96-100) over ray batches and `Renderer.render`
+mirrors Renderer::render (raytracer/src/lib/renderer/Renderer.h:17).  Errors of the C ABI are
+raised as the exception types the reference throws (std::invalid_argument -> ValueError,
+std::runtime_error -> RuntimeError).
+
+There is no CPU path: importing works without a GPU (so the ABI can be inspected), but every
+compute call needs librtgpu.so and a gfx950 device and fails loudly otherwise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librtgpu.so")
+
+EXPORTS = [
+    "rtgpu_last_error", "rtgpu_device_count", "rtgpu_set_device", "rtgpu_scene_create", "rtgpu_scene_destroy",
+    "rtgpu_trace_closest", "rtgpu_trace_closest_device", "rtgpu_trace_any", "rtgpu_trace_any_device",
+    "rtgpu_generate_primary_device", "rtgpu_render", "rtgpu_render_device", "rtgpu_camera_from_transform",
+    "rtgpu_scene_get_info", "rtgpu_trace_closest_count_device",
+]
+
+_lib = None
+
+
+class RtgpuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Loads librtgpu.so (built in-tree by `make -C raytracer_amd/csrc`)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RtgpuError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
+                         "(there is no CPU fallback for the ray-tracing path)")
+    L = C.CDLL(LIB_PATH)
+    fp, u32p, u8p, vp = abi.c_float_p, abi.c_u32_p, abi.c_u8_p, C.c_void_p
+    L.rtgpu_last_error.restype = C.c_char_p
+    L.rtgpu_device_count.restype = C.c_int
+    L.rtgpu_set_device.argtypes = [C.c_int]
+    L.rtgpu_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.POINTER(vp)]
+    L.rtgpu_scene_destroy.argtypes = [vp]
+    L.rtgpu_scene_destroy.restype = None
+    L.rtgpu_trace_closest.argtypes = [vp, fp, fp, C.c_uint64, vp]
+    L.rtgpu_trace_closest_device.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rtgpu_trace_any.argtypes = [vp, fp, fp, fp, C.c_uint64, u8p]
+    L.rtgpu_trace_any_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp]
+    L.rtgpu_generate_primary_device.argtypes = [C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int32, vp, vp, vp]
+    L.rtgpu_render.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), fp,
+                               C.POINTER(abi.RenderStats), abi.PROGRESS_CB, vp]
+    L.rtgpu_render_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp,
+                                      C.POINTER(abi.RenderStats), vp]
+    L.rtgpu_camera_from_transform.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(abi.Camera)]
+    L.rtgpu_scene_get_info.argtypes = [vp, C.POINTER(abi.SceneInfo)]
+    L.rtgpu_trace_closest_count_device.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc == 0:
+        return
+    msg = lib().rtgpu_last_error().decode("utf-8", "replace")
+    if rc == 1:
+        raise ValueError(msg)              # std::invalid_argument
+    if rc == 4:
+        raise MemoryError(msg)
+    raise RtgpuError(f"rtgpu error {rc}: {msg}")  # std::runtime_error
+
+
+def device_count() -> int:
+    return int(lib().rtgpu_device_count())
+
+
+def set_device(device: int):
+    _check(lib().rtgpu_set_device(int(device)))
+
+
+def camera_from_transform(fov_x_degrees: float, transform) -> abi.Camera:
+    """PerspectiveCamera(fov) + setTransform (camera/PerspectiveCamera.cpp:7-19)."""
+    cam = abi.Camera()
+    m = (C.c_double * 16)(*np.asarray(transform, dtype=np.float64).reshape(-1).tolist())
+    _check(lib().rtgpu_camera_from_transform(float(fov_x_degrees), m, C.byref(cam)))
+    return cam
+
+
+def _f32(a, cols=3):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    return a.reshape(-1, cols) if cols else a.reshape(-1)
+
+
+def _ptr(t):
+    """Device pointer of a torch tensor (or a raw int)."""
+    return C.c_void_p(int(t) if isinstance(t, int) else int(t.data_ptr()))
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        return C.c_void_p(0)
+    return C.c_void_p(int(stream if isinstance(stream, int) else stream.cuda_stream))
+
+
+class Scene:
+    """A built, GPU-resident scene (the reference's Scene after DynamicScene::build)."""
+
+    def __init__(self, scene: abi.SceneData):
+        self._packed = abi.PackedScene(scene)
+        h = C.c_void_p()
+        _check(lib().rtgpu_scene_create(C.byref(self._packed.desc), C.byref(h)))
+        self._h = h
+        self._packed = None  # the library copied everything it needs
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtgpu_scene_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    @property
+    def handle(self):
+        return self._h
+
+    def info(self) -> abi.SceneInfo:
+        out = abi.SceneInfo()
+        _check(lib().rtgpu_scene_get_info(self._h, C.byref(out)))
+        return out
+
+    # ---- Scene::traceRay / traceRays ---------------------------------------------------
+    def trace_rays(self, origins, dirs) -> np.ndarray:
+        o, d = _f32(origins), _f32(dirs)
+        if o.shape != d.shape:
+            raise ValueError("origins and directions must have the same shape")
+        out = np.empty(o.shape[0], dtype=abi.HIT_DTYPE)
+        _check(lib().rtgpu_trace_closest(self._h, o.ctypes.data_as(abi.c_float_p), d.ctypes.data_as(abi.c_float_p),
+                                         o.shape[0], C.c_void_p(out.ctypes.data)))
+        return out
+
+    def trace_ray(self, origin, direction):
+        h = self.trace_rays(np.asarray(origin).reshape(1, 3), np.asarray(direction).reshape(1, 3))[0]
+        return None if h["inst"] == abi.INVALID_ID else h  # std::optional<SceneRayHitInfo>
+
+    def trace_rays_device(self, d_origins, d_dirs, n, d_hits, stream=None):
+        _check(lib().rtgpu_trace_closest_device(self._h, _ptr(d_origins), _ptr(d_dirs), int(n), _ptr(d_hits), _stream_ptr(stream)))
+
+    def trace_counts_device(self, d_origins, d_dirs, n, d_counts, stream=None):
+        _check(lib().rtgpu_trace_closest_count_device(self._h, _ptr(d_origins), _ptr(d_dirs), int(n), _ptr(d_counts), _stream_ptr(stream)))
+
+    # ---- Scene::testVisibility ---------------------------------------------------------
+    def test_visibility(self, origins, dirs, max_t) -> np.ndarray:
+        o, d = _f32(origins), _f32(dirs)
+        t = _f32(np.broadcast_to(np.asarray(max_t, dtype=np.float32), (o.shape[0],)), cols=0)
+        if o.shape != d.shape:
+            raise ValueError("origins and directions must have the same shape")
+        out = np.empty(o.shape[0], dtype=np.uint8)
+        _check(lib().rtgpu_trace_any(self._h, o.ctypes.data_as(abi.c_float_p), d.ctypes.data_as(abi.c_float_p),
+                                     t.ctypes.data_as(abi.c_float_p), o.shape[0], out.ctypes.data_as(abi.c_u8_p)))
+        return out
+
+    def test_visibility_device(self, d_origins, d_dirs, d_tmax, n, d_occluded, stream=None):
+        _check(lib().rtgpu_trace_any_device(self._h, _ptr(d_origins), _ptr(d_dirs), _ptr(d_tmax), int(n), _ptr(d_occluded), _stream_ptr(stream)))
+
+
+def generate_primary_device(cam: abi.Camera, st: abi.RenderSettings, sample_index, d_origins, d_dirs, stream=None):
+    _check(lib().rtgpu_generate_primary_device(C.byref(cam), C.byref(st), int(sample_index), _ptr(d_origins), _ptr(d_dirs), _stream_ptr(stream)))
+
+
+class Renderer:
+    """Renderer::render (renderer/Renderer.cpp:273-304)."""
+
+    def render(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, framebuffer=None, progress=None):
+        """Renders the tile of `settings` into `framebuffer` ((H, W, 3) float32, created when None).
+        Returns (framebuffer, RenderStats)."""
+        if framebuffer is None:
+            framebuffer = np.zeros((settings.height, settings.width, 3), dtype=np.float32)
+        if framebuffer.dtype != np.float32 or framebuffer.shape != (settings.height, settings.width, 3) or not framebuffer.flags.c_contiguous:
+            raise ValueError("framebuffer must be a C-contiguous (H, W, 3) float32 array")
+        stats = abi.RenderStats()
+        cb = abi.PROGRESS_CB(lambda job, frac, fin, user: progress(job.decode(), frac, bool(fin))) if progress else abi.PROGRESS_CB()
+        _check(lib().rtgpu_render(scene.handle, C.byref(cam), C.byref(settings), framebuffer.ctypes.data_as(abi.c_float_p),
+                                  C.byref(stats), cb, None))
+        return framebuffer, stats
+
+    def render_device(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, d_framebuffer, stream=None):
+        stats = abi.RenderStats()
+        _check(lib().rtgpu_render_device(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), C.byref(stats), _stream_ptr(stream)))
+        return stats

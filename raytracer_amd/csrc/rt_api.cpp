@@ -1,0 +1,581 @@
+// rt_api.cpp -- implementation of the C ABI declared in include/rtgpu.h (host side, HIP runtime).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/rtgpu.h"
+#include "bvh_build.h"
+#include "rt_device.h"
+#include "rt_scene.h"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg)
+{
+    g_error = msg;
+    return code;
+}
+
+#define RT_HIP(call)                                                                                         \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess)                                                                                \
+            return fail(e_ == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP,                 \
+                        std::string(#call) + ": " + hipGetErrorString(e_));                                  \
+    } while (0)
+
+template <typename F>
+void parallel_for(size_t n, int threads, const F& f)
+{
+    if (threads <= 1 || n < 4096) {
+        f(0, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t chunk = (n + threads - 1) / threads;
+    for (int t = 0; t < threads; ++t) {
+        size_t b = (size_t)t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        th.emplace_back([&f, b, e] { f(b, e); });
+    }
+    for (auto& t : th) t.join();
+}
+
+// Transformation::transform(Point), math/Transformation.h:71-76
+void xf_point(const double* M, const float p[3], float out[3])
+{
+    double v[4];
+    for (int i = 0; i < 4; ++i) v[i] = ((M[i * 4 + 0] * p[0] + M[i * 4 + 1] * p[1]) + M[i * 4 + 2] * p[2]) + M[i * 4 + 3] * 1.0;
+    for (int i = 0; i < 3; ++i) out[i] = (float)(v[i] / v[3]);
+}
+// Transformation::transform(Vector3), math/Transformation.h:83-87
+void xf_vector(const double* M, const float p[3], float out[3])
+{
+    for (int i = 0; i < 3; ++i) out[i] = (float)(((M[i * 4 + 0] * p[0] + M[i * 4 + 1] * p[1]) + M[i * 4 + 2] * p[2]) + M[i * 4 + 3] * 0.0);
+}
+
+bool affine(const double* m) { return m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0; }
+
+template <typename T>
+int upload(const std::vector<T>& v, const T** out, uint64_t& bytes)
+{
+    *out = nullptr;
+    if (v.empty()) return RTGPU_OK;
+    void* p = nullptr;
+    RT_HIP(hipMalloc(&p, v.size() * sizeof(T)));
+    *out = (const T*)p;
+    bytes += v.size() * sizeof(T);
+    RT_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
+    return RTGPU_OK;
+}
+
+int validate(const rtgpu_scene_desc* d)
+{
+    if (!d) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene description is null");
+    if (d->n_instances == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene has no instances");
+    if (d->n_instances >= (1u << 27)) return fail(RTGPU_ERR_LIMIT, "more than 2^27 instances");
+    if ((d->n_meshes && !d->meshes) || !d->instances) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null mesh/instance array");
+    if (d->n_materials == 0 || !d->materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene has no materials");
+    if ((d->n_point_lights && !d->point_lights) || (d->n_area_lights && !d->area_lights))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "null light array");
+    for (uint32_t m = 0; m < d->n_meshes; ++m) {
+        const rtgpu_mesh_desc& md = d->meshes[m];
+        if (md.n_triangles == 0 || md.n_vertices == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mesh is empty"); // std::runtime_error("mesh is empty"), shape/TriangleMesh.cpp:63-65
+        if (md.n_triangles >= (1u << 27)) return fail(RTGPU_ERR_LIMIT, "mesh has more than 2^27 triangles");
+        if (!md.vertices || !md.indices || !md.normals) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mesh arrays must not be null");
+        for (size_t i = 0; i < (size_t)md.n_triangles * 3; ++i)
+            if (md.indices[i] >= md.n_vertices) return fail(RTGPU_ERR_INVALID_ARGUMENT, "triangle index out of range");
+        if (md.tri_material)
+            for (uint32_t i = 0; i < md.n_triangles; ++i)
+                if (md.tri_material[i] >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "triangle material id out of range");
+        for (size_t i = 0; i < (size_t)md.n_vertices * 3; ++i)
+            if (std::isnan(md.vertices[i])) return fail(RTGPU_ERR_INVALID_ARGUMENT, "NaN vertex"); // assert(!hasNaN), shape/AABB.cpp:15-16
+    }
+    for (uint32_t i = 0; i < d->n_instances; ++i) {
+        const rtgpu_instance_desc& id = d->instances[i];
+        if (id.shape != RTGPU_SHAPE_SPHERE && (id.shape < 0 || (uint32_t)id.shape >= d->n_meshes))
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance shape index out of range");
+        if (id.material >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance material id out of range");
+        if (!affine(id.transform) || !affine(id.inverse))
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance transforms must be affine (last row 0 0 0 1)");
+    }
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        const rtgpu_material& m = d->materials[i];
+        if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_CONSTMIX) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
+        if (m.type == RTGPU_MAT_CONSTMIX) {
+            if (m.first >= d->n_materials || m.second >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix material child out of range");
+            // nested mixes are resolved at most kMaxMixDepth deep on the device
+            uint32_t depth = 0, cur = i;
+            while (d->materials[cur].type == RTGPU_MAT_CONSTMIX && depth <= 4) { cur = d->materials[cur].first; ++depth; }
+            if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
+            depth = 0; cur = i;
+            while (d->materials[cur].type == RTGPU_MAT_CONSTMIX && depth <= 4) { cur = d->materials[cur].second; ++depth; }
+            if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
+        }
+    }
+    return RTGPU_OK;
+}
+
+int ceil_log2(uint32_t n)
+{
+    int l = 0;
+    while ((1u << l) < n) ++l;
+    return l;
+}
+
+} // namespace
+
+void rtgpu_scene::release()
+{
+    (void)hipSetDevice(device);
+    const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
+                          view.materials, view.pointLights, view.areaLights};
+    for (const void* p : ptrs)
+        if (p) (void)hipFree(const_cast<void*>(p));
+    view = rt::SceneView{};
+}
+
+extern "C" {
+
+const char* rtgpu_last_error(void) { return g_error.c_str(); }
+
+int rtgpu_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int rtgpu_set_device(int device)
+{
+    RT_HIP(hipSetDevice(device));
+    return RTGPU_OK;
+}
+
+int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
+{
+    using namespace rt;
+    if (!out_scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "out_scene is null");
+    *out_scene = nullptr;
+    if (int rc = validate(desc)) return rc;
+    int device = 0;
+    if (hipGetDevice(&device) != hipSuccess) return fail(RTGPU_ERR_NO_DEVICE, "no HIP device available");
+
+    const auto t0 = std::chrono::steady_clock::now();
+    const int threads = std::max(1u, std::min(64u, std::thread::hardware_concurrency()));
+    const uint32_t nInst = desc->n_instances;
+    const bool singleMesh = nInst == 1 && desc->instances[0].shape >= 0;
+
+    // ---- top-level tree over the instances' world boxes (built first: its depth fixes the budget
+    // the mesh trees get from the shared per-lane stack) --------------------------------------
+    // per-mesh boxes are needed first
+    struct MeshBox { float lo[3], hi[3]; };
+    std::vector<std::vector<PrimBox>> primBoxes(desc->n_meshes);
+    std::vector<MeshBox> meshBox(desc->n_meshes);
+    for (uint32_t m = 0; m < desc->n_meshes; ++m) {
+        const rtgpu_mesh_desc& md = desc->meshes[m];
+        auto& pb = primBoxes[m];
+        pb.resize(md.n_triangles);
+        parallel_for(md.n_triangles, threads, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                // TriangleMesh::getAABB(i), shape/TriangleMesh.cpp:177-191: min/max of the vertices
+                // padded by 1e-4 (added in double, narrowed to float)
+                const float* p1 = md.vertices + 3 * (size_t)md.indices[3 * i];
+                const float* p2 = md.vertices + 3 * (size_t)md.indices[3 * i + 1];
+                const float* p3 = md.vertices + 3 * (size_t)md.indices[3 * i + 2];
+                for (int a = 0; a < 3; ++a) {
+                    float lo = std::min({p1[a], p2[a], p3[a]}), hi = std::max({p1[a], p2[a], p3[a]});
+                    pb[i].lo[a] = (float)(lo - 1E-4);
+                    pb[i].hi[a] = (float)(hi + 1E-4);
+                }
+            }
+        });
+        MeshBox mb;
+        for (int a = 0; a < 3; ++a) { mb.lo[a] = INFINITY; mb.hi[a] = -INFINITY; }
+        for (const PrimBox& p : pb)
+            for (int a = 0; a < 3; ++a) { mb.lo[a] = std::min(mb.lo[a], p.lo[a]); mb.hi[a] = std::max(mb.hi[a], p.hi[a]); }
+        meshBox[m] = mb;
+    }
+    std::vector<DevInstance> inst(nInst);
+    std::vector<PrimBox> instBoxes(nInst);
+    for (uint32_t i = 0; i < nInst; ++i) {
+        const rtgpu_instance_desc& id = desc->instances[i];
+        DevInstance& di = inst[i];
+        std::memcpy(di.inv, id.inverse, sizeof(double) * 12);
+        di.shape = id.shape;
+        di.material = id.material;
+        di.root = 0; di.triBase = 0; di.meshVertBase = 0; di.pad = 0;
+        // InstancedModelList::getAABB (shape/list/InstancedModelList.cpp:21-26) =
+        // AABB::getAABBOfTransformed (shape/AABB.cpp:33-46) of the shape's box; a sphere declares
+        // +-0.5 (shape/Sphere.cpp:11-14)
+        float lo[3], hi[3];
+        if (id.shape >= 0) { std::memcpy(lo, meshBox[id.shape].lo, 12); std::memcpy(hi, meshBox[id.shape].hi, 12); }
+        else { lo[0] = lo[1] = lo[2] = -0.5f; hi[0] = hi[1] = hi[2] = 0.5f; }
+        float wlo[3] = {INFINITY, INFINITY, INFINITY}, whi[3] = {-INFINITY, -INFINITY, -INFINITY};
+        for (int c = 0; c < 8; ++c) {
+            float p[3] = {(c & 1) ? hi[0] : lo[0], (c & 2) ? hi[1] : lo[1], (c & 4) ? hi[2] : lo[2]}, q[3];
+            xf_point(id.transform, p, q);
+            for (int a = 0; a < 3; ++a) { wlo[a] = std::min(wlo[a], q[a]); whi[a] = std::max(whi[a], q[a]); }
+        }
+        for (int a = 0; a < 3; ++a) {
+            if (std::isnan(wlo[a]) || std::isnan(whi[a])) return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance box is NaN");
+            di.wlo[a] = instBoxes[i].lo[a] = wlo[a];
+            di.whi[a] = instBoxes[i].hi[a] = whi[a];
+        }
+    }
+    BuiltTree top;
+    int meshDepthBudget = kStackDepth - 1;
+    if (nInst > 1) {
+        BuildParams tp;
+        tp.maxLeaf = 1;
+        tp.maxLeafHard = 1;
+        tp.threads = threads;
+        tp.maxDepth = std::min(24, ceil_log2(nInst) + 4);
+        top = build_tree(instBoxes.data(), nInst, tp);
+        meshDepthBudget = kStackDepth - 1 - (int)top.maxDepth; // one entry for the mesh-tree sentinel
+    }
+
+    // ---- mesh trees ------------------------------------------------------------------------
+    std::vector<Node64> nodes;
+    std::vector<TriRec> tris;
+    std::vector<uint32_t> triIds, triMat;
+    std::vector<float> vertNormals;
+    std::vector<uint32_t> meshRoot(desc->n_meshes), meshTriBase(desc->n_meshes);
+    rtgpu_scene_info info{};
+    bool anyTriMat = false;
+    for (uint32_t m = 0; m < desc->n_meshes; ++m)
+        if (desc->meshes[m].tri_material) anyTriMat = true;
+    for (uint32_t m = 0; m < desc->n_meshes; ++m) {
+        const rtgpu_mesh_desc& md = desc->meshes[m];
+        BuildParams bp;
+        bp.threads = threads;
+        bp.maxDepth = meshDepthBudget;
+        const int need = ceil_log2((md.n_triangles + kMaxLeafHard - 1) / kMaxLeafHard);
+        if (need > meshDepthBudget) return fail(RTGPU_ERR_LIMIT, "scene too deep for the traversal stack");
+        BuiltTree bt = build_tree(primBoxes[m].data(), md.n_triangles, bp);
+        primBoxes[m].clear();
+        primBoxes[m].shrink_to_fit();
+        meshRoot[m] = (uint32_t)nodes.size();
+        meshTriBase[m] = (uint32_t)tris.size();
+        nodes.insert(nodes.end(), bt.nodes.begin(), bt.nodes.end());
+        const size_t base = tris.size();
+        tris.resize(base + md.n_triangles);
+        triIds.resize(base + md.n_triangles);
+        vertNormals.resize((base + md.n_triangles) * 9);
+        if (anyTriMat) triMat.resize(base + md.n_triangles);
+        parallel_for(md.n_triangles, threads, [&](size_t b, size_t e) {
+            for (size_t s = b; s < e; ++s) {
+                const uint32_t tri = bt.order[s];
+                const uint32_t i0 = md.indices[3 * (size_t)tri], i1 = md.indices[3 * (size_t)tri + 1], i2 = md.indices[3 * (size_t)tri + 2];
+                const float* a = md.vertices + 3 * (size_t)i0;
+                const float* bb = md.vertices + 3 * (size_t)i1;
+                const float* c = md.vertices + 3 * (size_t)i2;
+                TriRec r;
+                r.ax = a[0]; r.ay = a[1]; r.az = a[2];
+                r.e1x = a[0] - bb[0]; r.e1y = a[1] - bb[1]; r.e1z = a[2] - bb[2]; // e1 = a - b, math/Triangle.h:38
+                r.e2x = a[0] - c[0]; r.e2y = a[1] - c[1]; r.e2z = a[2] - c[2];    // e2 = a - c, math/Triangle.h:39
+                // cofactors of rows (e1, e2) in Eigen's 3x3 determinant expansion
+                r.c0 = r.e1y * r.e2z - r.e1z * r.e2y;
+                r.c1 = r.e1x * r.e2z - r.e1z * r.e2x;
+                r.c2 = r.e1x * r.e2y - r.e1y * r.e2x;
+                tris[base + s] = r;
+                triIds[base + s] = tri;
+                float* vn = vertNormals.data() + (base + s) * 9;
+                std::memcpy(vn, md.normals + 3 * (size_t)i0, 12);
+                std::memcpy(vn + 3, md.normals + 3 * (size_t)i1, 12);
+                std::memcpy(vn + 6, md.normals + 3 * (size_t)i2, 12);
+                if (anyTriMat) triMat[base + s] = md.tri_material ? md.tri_material[tri] : kInvalid;
+            }
+        });
+        info.n_triangles += md.n_triangles;
+        info.n_leaves += bt.leafCount;
+        info.max_depth = std::max(info.max_depth, bt.maxDepth);
+        info.max_leaf_size = std::max(info.max_leaf_size, bt.maxLeafSize);
+    }
+    const uint32_t topRoot = (uint32_t)nodes.size();
+    std::vector<uint32_t> instOrder(nInst);
+    for (uint32_t i = 0; i < nInst; ++i) instOrder[i] = i;
+    if (nInst > 1) {
+        nodes.insert(nodes.end(), top.nodes.begin(), top.nodes.end());
+        instOrder = top.order;
+        info.n_leaves += top.leafCount;
+        info.max_depth = std::max(info.max_depth, top.maxDepth + 1 + info.max_depth);
+    }
+    if (nodes.size() >= (1ull << 31)) return fail(RTGPU_ERR_LIMIT, "more than 2^31 tree nodes");
+    info.n_nodes = nodes.size();
+    for (uint32_t i = 0; i < nInst; ++i) {
+        if (inst[i].shape >= 0) {
+            inst[i].root = meshRoot[inst[i].shape];
+            inst[i].triBase = meshTriBase[inst[i].shape];
+        }
+    }
+    // ---- materials and lights --------------------------------------------------------------
+    std::vector<DevMaterial> mats(desc->n_materials);
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
+        const rtgpu_material& m = desc->materials[i];
+        DevMaterial& dm = mats[i];
+        dm.type = m.type;
+        std::memcpy(dm.color, m.color, 12);
+        dm.roughness = m.roughness;
+        dm.mixFactor = (float)m.mix_factor; // calcMixFactor returns float, material/MixMaterial.h:21-25
+        dm.first = m.first;
+        dm.second = m.second;
+        dm.intensity = m.intensity;
+    }
+    std::vector<DevPointLight> pls(desc->n_point_lights);
+    for (uint32_t i = 0; i < desc->n_point_lights; ++i) {
+        std::memcpy(pls[i].pos, desc->point_lights[i].pos, 12);
+        std::memcpy(pls[i].color, desc->point_lights[i].color, 12);
+        pls[i].intensity = desc->point_lights[i].intensity;
+    }
+    std::vector<DevAreaLight> als(desc->n_area_lights);
+    for (uint32_t i = 0; i < desc->n_area_lights; ++i) {
+        const rtgpu_area_light& L = desc->area_lights[i];
+        DevAreaLight& d = als[i];
+        std::memcpy(d.a, L.a, 12); std::memcpy(d.b, L.b, 12); std::memcpy(d.c, L.c, 12);
+        std::memcpy(d.color, L.color, 12);
+        d.intensity = L.intensity;
+        rt::area_light_derived(d);
+    }
+
+    const auto t1 = std::chrono::steady_clock::now();
+    info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+
+    auto* sc = new rtgpu_scene();
+    sc->device = device;
+    SceneView& v = sc->view;
+    v = SceneView{};
+    uint64_t bytes = 0;
+    int rc;
+    const float4* p4;
+    if ((rc = upload(nodes, (const Node64**)&p4, bytes))) { sc->release(); delete sc; return rc; }
+    v.nodes = p4;
+    if ((rc = upload(tris, (const TriRec**)&p4, bytes))) { sc->release(); delete sc; return rc; }
+    v.tris = p4;
+    if ((rc = upload(triIds, &v.triIds, bytes)) || (rc = upload(inst, &v.inst, bytes)) || (rc = upload(instOrder, &v.instOrder, bytes)) ||
+        (rc = upload(vertNormals, &v.vertNormals, bytes)) || (rc = upload(triMat, &v.triMaterial, bytes)) ||
+        (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
+        (rc = upload(als, &v.areaLights, bytes))) {
+        sc->release();
+        delete sc;
+        return rc;
+    }
+    v.nInst = nInst;
+    v.topRoot = topRoot;
+    v.singleMesh = singleMesh ? 1u : 0u;
+    v.nMaterials = desc->n_materials;
+    v.nPointLights = desc->n_point_lights;
+    v.nAreaLights = desc->n_area_lights;
+    v.hasEnv = desc->has_environment ? 1 : 0;
+    // ColorEnvironment::getRadiance = color * intensity (RGB * double), ColorEnvironment.cpp:6-9
+    for (int a = 0; a < 3; ++a) v.envRadiance[a] = (float)((double)desc->env_color[a] * desc->env_intensity);
+    info.device_bytes = bytes;
+    sc->info = info;
+    *out_scene = sc;
+    return RTGPU_OK;
+}
+
+void rtgpu_scene_destroy(rtgpu_scene* scene)
+{
+    if (!scene) return;
+    scene->release();
+    delete scene;
+}
+
+int rtgpu_scene_get_info(const rtgpu_scene* scene, rtgpu_scene_info* out)
+{
+    if (!scene || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null argument");
+    *out = scene->info;
+    return RTGPU_OK;
+}
+
+int rtgpu_trace_closest_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                               uint64_t n, rtgpu_hit* d_out_hits, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n && (!d_origins || !d_dirs || !d_out_hits)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/hit buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt::launch_trace_closest(scene->view, d_origins, d_dirs, n, d_out_hits, nullptr, (hipStream_t)hip_stream));
+    return RTGPU_OK;
+}
+
+int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                                     uint64_t n, uint32_t* d_counts, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n && (!d_origins || !d_dirs || !d_counts)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/count buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    rtgpu_hit* tmp = nullptr;
+    RT_HIP(hipMalloc((void**)&tmp, std::max<uint64_t>(1, n) * sizeof(rtgpu_hit)));
+    hipError_t e = rt::launch_trace_closest(scene->view, d_origins, d_dirs, n, tmp, d_counts, (hipStream_t)hip_stream);
+    hipError_t e2 = hipStreamSynchronize((hipStream_t)hip_stream);
+    (void)hipFree(tmp);
+    RT_HIP(e);
+    RT_HIP(e2);
+    return RTGPU_OK;
+}
+
+int rtgpu_trace_any_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
+                           const float* d_tmax, uint64_t n, uint8_t* d_out_occluded, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n && (!d_origins || !d_dirs || !d_tmax || !d_out_occluded)) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/result buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    RT_HIP(rt::launch_trace_any(scene->view, d_origins, d_dirs, d_tmax, n, d_out_occluded, (hipStream_t)hip_stream));
+    return RTGPU_OK;
+}
+
+namespace {
+struct DevBuf {
+    void* p = nullptr;
+    ~DevBuf() { if (p) (void)hipFree(p); }
+};
+constexpr uint64_t kHostChunk = 1ull << 24; // rays per staged chunk of the host-pointer entry points
+} // namespace
+
+int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const float* dirs, uint64_t n, rtgpu_hit* out_hits)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n == 0) return RTGPU_OK;
+    if (!origins || !dirs || !out_hits) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/hit buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    const uint64_t cap = std::min(n, kHostChunk);
+    DevBuf dO, dD, dH;
+    RT_HIP(hipMalloc(&dO.p, cap * 12));
+    RT_HIP(hipMalloc(&dD.p, cap * 12));
+    RT_HIP(hipMalloc(&dH.p, cap * sizeof(rtgpu_hit)));
+    for (uint64_t b = 0; b < n; b += cap) {
+        const uint64_t m = std::min(cap, n - b);
+        RT_HIP(hipMemcpy(dO.p, origins + 3 * b, m * 12, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
+        RT_HIP(rt::launch_trace_closest(scene->view, (const float*)dO.p, (const float*)dD.p, m, (rtgpu_hit*)dH.p, nullptr, nullptr));
+        RT_HIP(hipMemcpy(out_hits + b, dH.p, m * sizeof(rtgpu_hit), hipMemcpyDeviceToHost));
+    }
+    return RTGPU_OK;
+}
+
+int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float* dirs, const float* tmax, uint64_t n, uint8_t* out_occluded)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n == 0) return RTGPU_OK;
+    if (!origins || !dirs || !tmax || !out_occluded) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/result buffer");
+    RT_HIP(hipSetDevice(scene->device));
+    const uint64_t cap = std::min(n, kHostChunk);
+    DevBuf dO, dD, dT, dR;
+    RT_HIP(hipMalloc(&dO.p, cap * 12));
+    RT_HIP(hipMalloc(&dD.p, cap * 12));
+    RT_HIP(hipMalloc(&dT.p, cap * 4));
+    RT_HIP(hipMalloc(&dR.p, cap));
+    for (uint64_t b = 0; b < n; b += cap) {
+        const uint64_t m = std::min(cap, n - b);
+        RT_HIP(hipMemcpy(dO.p, origins + 3 * b, m * 12, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
+        RT_HIP(hipMemcpy(dT.p, tmax + b, m * 4, hipMemcpyHostToDevice));
+        RT_HIP(rt::launch_trace_any(scene->view, (const float*)dO.p, (const float*)dD.p, (const float*)dT.p, m, (uint8_t*)dR.p, nullptr));
+        RT_HIP(hipMemcpy(out_occluded + b, dR.p, m, hipMemcpyDeviceToHost));
+    }
+    return RTGPU_OK;
+}
+
+static int check_settings(const rtgpu_render_settings* st)
+{
+    if (!st) return fail(RTGPU_ERR_INVALID_ARGUMENT, "settings are null");
+    if (st->width <= 0 || st->height <= 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "resolution must be positive"); // film/FrameBuffer.cpp:9-14
+    if (st->x_start > st->x_end || st->y_start > st->y_end) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid tile bounds"); // film/Tile.cpp:9-12
+    if (st->x_start < 0 || st->y_start < 0 || st->x_end > st->width || st->y_end > st->height)
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "tile outside the frame buffer");
+    if (st->geometry_aa < 1 || st->material_aa < 1 || st->max_path_length < 1)
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "sample counts and path length must be >= 1");
+    if ((int64_t)st->geometry_aa * st->material_aa > (1ll << 31)) return fail(RTGPU_ERR_LIMIT, "geometry_aa * material_aa exceeds 2^31");
+    if (st->max_path_length > 64) return fail(RTGPU_ERR_LIMIT, "max_path_length exceeds 64");
+    if (st->jitter_mode != RTGPU_JITTER_RANDOM && st->jitter_mode != RTGPU_JITTER_CENTER)
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown jitter mode");
+    return RTGPU_OK;
+}
+
+int rtgpu_generate_primary_device(const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                                  int32_t sample_index, float* d_origins, float* d_dirs, void* hip_stream)
+{
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (camera->aperture != 0.0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "thin-lens cameras (aperture > 0) are not supported");
+    if (!d_origins || !d_dirs) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray buffer");
+    RT_HIP(rt::launch_generate_primary(*camera, *settings, sample_index, d_origins, d_dirs, (hipStream_t)hip_stream));
+    return RTGPU_OK;
+}
+
+int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                        float* d_rgb_out, rtgpu_render_stats* stats, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (camera->aperture != 0.0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "thin-lens cameras (aperture > 0) are not supported");
+    if (!d_rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
+    RT_HIP(hipSetDevice(scene->device));
+    std::string err;
+    hipError_t e = rt::render_wavefront(*scene, *camera, *settings, d_rgb_out, stats, (hipStream_t)hip_stream, err);
+    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+    return RTGPU_OK;
+}
+
+int rtgpu_render(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                 float* rgb_out, rtgpu_render_stats* stats, rtgpu_progress_cb progress, void* user)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (!rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
+    RT_HIP(hipSetDevice(scene->device));
+    const size_t bytes = (size_t)settings->width * settings->height * 3 * sizeof(float);
+    DevBuf fb;
+    RT_HIP(hipMalloc(&fb.p, bytes));
+    // pixels outside the tile keep the caller's values (Renderer::render only writes inside the tile)
+    RT_HIP(hipMemcpy(fb.p, rgb_out, bytes, hipMemcpyHostToDevice));
+    if (progress) progress("Rendering tiles", 0.0f, 0, user);
+    if (int rc = rtgpu_render_device(scene, camera, settings, (float*)fb.p, stats, nullptr)) return rc;
+    RT_HIP(hipMemcpy(rgb_out, fb.p, bytes, hipMemcpyDeviceToHost));
+    if (progress) progress("Rendering tiles", 1.0f, 1, user);
+    return RTGPU_OK;
+}
+
+// PerspectiveCamera(fov) + setTransform, camera/PerspectiveCamera.cpp:7-19, with
+// OrthonormalBasis(a, b), math/OrthonormalBasis.cpp:33-51.
+int rtgpu_camera_from_transform(double fov_x_degrees, const double transform[16], rtgpu_camera* out)
+{
+    if (!transform || !out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null argument");
+    const double PI = 3.14159265358979323;
+    out->width = 2.0 * std::tan(0.5 * (fov_x_degrees * PI / 180.0));
+    const float zero[3] = {0, 0, 0}, fwd[3] = {0, 0, -1}, upv[3] = {0, 1, 0};
+    float origin[3], lookat[3], up[3];
+    xf_point(transform, zero, origin);
+    xf_vector(transform, fwd, lookat);
+    xf_vector(transform, upv, up);
+    const float a[3] = {-lookat[0], -lookat[1], -lookat[2]};
+    // cross = b x a
+    float cr[3] = {up[1] * a[2] - up[2] * a[1], up[2] * a[0] - up[0] * a[2], up[0] * a[1] - up[1] * a[0]};
+    const float len = std::sqrt(cr[0] * cr[0] + (cr[1] * cr[1] + cr[2] * cr[2]));
+    if (len == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "The vectors are colinear!"); // OrthonormalBasis.cpp:38-41
+    const float an2 = a[0] * a[0] + (a[1] * a[1] + a[2] * a[2]);
+    float w[3] = {a[0], a[1], a[2]};
+    if (an2 > 0) { const float an = std::sqrt(an2); for (float& c : w) c /= an; }
+    float u[3] = {cr[0] / len, cr[1] / len, cr[2] / len};
+    float v[3] = {w[1] * u[2] - w[2] * u[1], w[2] * u[0] - w[0] * u[2], w[0] * u[1] - w[1] * u[0]};
+    std::memcpy(out->origin, origin, 12);
+    std::memcpy(out->u, u, 12);
+    std::memcpy(out->v, v, 12);
+    std::memcpy(out->w, w, 12);
+    out->aperture = 0;
+    out->focal_distance = 0;
+    return RTGPU_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,65 @@
+// rt_device.h -- device-side scene view and the launch functions of the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/rtgpu.h"
+#include "rt_types.h"
+
+namespace rt {
+
+struct DevMaterial {
+    int32_t type;
+    float color[3];
+    float roughness;
+    float mixFactor;
+    uint32_t first, second;
+    double intensity;
+};
+
+struct DevPointLight {
+    float pos[3];
+    float color[3];
+    double intensity;
+};
+
+struct DevAreaLight {
+    float a[3], b[3], c[3];
+    float color[3];
+    double intensity;
+    float normal[3]; // AreaLight::getNormal, light/AreaLight.cpp:43-48
+    float area;      // Triangle::getSurfaceArea, math/Triangle.h:7-18
+};
+
+// Everything the kernels need, passed by value as a kernel argument.
+struct SceneView {
+    const float4* nodes;        // Node64 records as 4 x float4
+    const float4* tris;         // TriRec records as 3 x float4
+    const uint32_t* triIds;     // leaf slot -> caller's triangle index (per mesh, offset by triBase)
+    const DevInstance* inst;
+    const uint32_t* instOrder;  // top-level leaf slot -> instance index
+    uint32_t nInst;
+    uint32_t topRoot;           // first node of the top-level tree
+    uint32_t singleMesh;        // 1: exactly one instance and it is a mesh (no top-level tree walk)
+    // shade stage
+    const float* vertNormals;   // per leaf slot: 3 vertex normals (9 floats)
+    const uint32_t* triMaterial; // per leaf slot material id, or kInvalid -> instance material
+    const DevMaterial* materials;
+    const DevPointLight* pointLights;
+    const DevAreaLight* areaLights;
+    uint32_t nMaterials, nPointLights, nAreaLights;
+    int32_t hasEnv;
+    float envRadiance[3];
+};
+
+// Closest hit for n rays (Scene::traceRay).  counts may be null.
+hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const float* dD, uint64_t n,
+                                rtgpu_hit* dHits, uint32_t* dCounts, hipStream_t stream);
+// Any hit (Scene::testVisibility).
+hipError_t launch_trace_any(const SceneView& sv, const float* dO, const float* dD, const float* dTmax,
+                            uint64_t n, uint8_t* dOcc, hipStream_t stream);
+// PerspectiveCamera::generateRay over a tile.
+hipError_t launch_generate_primary(const rtgpu_camera& cam, const rtgpu_render_settings& st, int32_t sampleIndex,
+                                   float* dO, float* dD, hipStream_t stream);
+
+} // namespace rt

@@ -1,0 +1,73 @@
+// rt_rng_inl.h -- counter-based RNG, stratified samplers and the camera model (device side).
+//
+// The reference draws from a thread-local pcg32 seeded by std::random_device
+// (math/FastRandom.h:6-67), which cannot be reproduced or seeded.  Every Rand::unit() call site
+// is replaced by a pure function of (seed, pixel, sample, path vertex, dimension), so a pixel's
+// value does not depend on which GPU, tile or launch computes it.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_trace_inl.h"
+
+namespace rt {
+
+enum RngDim : uint32_t {
+    DIM_CAM_X = 0, DIM_CAM_Y = 1,
+    DIM_NEE_CHOICE = 1, DIM_LIGHT_TYPE = 2, DIM_LIGHT_INDEX = 3, DIM_AREA_U = 4, DIM_AREA_V = 5,
+    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_MIX0 = 12
+};
+constexpr uint32_t kVertexCamera = 255;
+
+__host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
+{
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+// Uniform float in [0,1) with 24 random bits, the stand-in for Rand::unit() (math/FastRandom.h:28-31).
+__host__ __device__ __forceinline__ float rand_unit(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t vertex, uint32_t dim)
+{
+    const uint64_t k1 = ((uint64_t)pixel << 32) | sample;
+    const uint64_t k2 = ((uint64_t)seed << 32) | (uint64_t)((vertex << 8) | dim);
+    const uint32_t x = (uint32_t)(splitmix64(splitmix64(k1) ^ k2) >> 32);
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
+
+// sampleUniformStratifiedSquare, math/Sampler.h:13-26 (r0, r1 are the two Rand::unit() draws).
+__device__ __forceinline__ void stratified_square(int level, float sampleI, float r0, float r1, float& sx, float& sy)
+{
+    if (level < 4) { sx = r0; sy = r1; return; }
+    const int binsPerAxis = (int)sqrt((double)level);
+    const float binX = (float)fmod((double)sampleI, (double)binsPerAxis);
+    const float binY = (float)floor(fmod((double)sampleI, (double)level) / binsPerAxis);
+    sx = (binX / binsPerAxis) + (r0 / binsPerAxis);
+    sy = (binY / binsPerAxis) + (r1 / binsPerAxis);
+}
+
+// PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52 (pinhole: aperture == 0).
+__device__ __forceinline__ void camera_ray(const rtgpu_camera& cam, const rtgpu_render_settings& st, int x, int y,
+                                           int sampleIndex, F3& o, F3& d)
+{
+    const uint32_t pixel = (uint32_t)(y * st.width + x);
+    float r0 = 0.5f, r1 = 0.5f;
+    if (st.jitter_mode == RTGPU_JITTER_RANDOM) {
+        const uint32_t sample = (uint32_t)(sampleIndex * st.material_aa);
+        r0 = rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_CAM_X);
+        r1 = rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_CAM_Y);
+    }
+    float sx, sy;
+    stratified_square(st.geometry_aa, (float)sampleIndex, r0, r1, sx, sy);
+    sx = (float)x + sx;
+    sy = (float)y + sy;
+    const double height = st.height * cam.width / st.width;
+    const double u = cam.width * (sx / st.width - 0.5);
+    const double v = -height * (sy / st.height - 0.5);
+    const F3 U = f3(cam.u[0], cam.u[1], cam.u[2]), V = f3(cam.v[0], cam.v[1], cam.v[2]), W = f3(cam.w[0], cam.w[1], cam.w[2]);
+    const F3 dir = ((U * (float)u) + (V * (float)v)) - W;
+    d = normalized3(dir);
+    o = f3(cam.origin[0], cam.origin[1], cam.origin[2]);
+}
+
+} // namespace rt

@@ -1,0 +1,26 @@
+// rt_scene.h -- the opaque scene handle of the C ABI and the host entry of the integrator.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/rtgpu.h"
+#include "rt_device.h"
+
+struct rtgpu_scene {
+    int device = 0;
+    rt::SceneView view{};
+    rtgpu_scene_info info{};
+    void release();
+};
+
+namespace rt {
+
+// Fills normal and area of an area light (AreaLight::getNormal / getSurfaceArea, light/AreaLight.cpp:43-53).
+void area_light_derived(DevAreaLight& l);
+
+// Renderer::render as a wavefront pipeline; writes the tile's pixels of the device frame buffer.
+hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st,
+                            float* dRgb, rtgpu_render_stats* stats, hipStream_t stream, std::string& err);
+
+} // namespace rt

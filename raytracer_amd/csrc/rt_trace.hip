@@ -1,0 +1,108 @@
+// rt_trace.hip -- batch closest-hit / any-hit kernels and the primary-ray generator (gfx950).
+//
+// Launch shape: one wave64 per workgroup (traversal has no intra-workgroup cooperation, so the
+// smallest workgroup gives the dispatcher the finest grain and frees the 8 KB LDS stack of a
+// finished wave at once), one ray per lane, grid = ceil(n / 64).
+#include <hip/hip_runtime.h>
+
+#include "rt_rng_inl.h"
+#include "rt_trace_inl.h"
+
+namespace rt {
+
+template <bool INSTANCED, bool COUNT>
+__global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const float* __restrict__ ro,
+                                                           const float* __restrict__ rd, uint64_t n,
+                                                           rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
+{
+    __shared__ int stack[kStackDepth][64];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    if (i >= n) return;
+    F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+    F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    uint32_t nb = 0, nt = 0;
+    TraceResult r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
+    rtgpu_hit h;
+    h.t = r.t;
+    h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
+    h.inst = r.inst;
+    h.beta = r.beta;
+    h.gamma = r.gamma;
+    out[i] = h;
+    if (COUNT) {
+        counts[2 * i] = nb;
+        counts[2 * i + 1] = nt;
+    }
+}
+
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void trace_any_kernel(SceneView sv, const float* __restrict__ ro,
+                                                       const float* __restrict__ rd, const float* __restrict__ tmax,
+                                                       uint64_t n, uint8_t* __restrict__ occ)
+{
+    __shared__ int stack[kStackDepth][64];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    if (i >= n) return;
+    F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+    F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    uint32_t nb = 0, nt = 0;
+    TraceResult r = trace_ray<INSTANCED, true, false>(sv, o, d, tmax[i], stack, lane, nb, nt);
+    occ[i] = r.inst != kInvalid ? 1 : 0;
+}
+
+// PerspectiveCamera::generateRay (camera/PerspectiveCamera.cpp:26-52), aperture 0.
+__global__ __launch_bounds__(256) void generate_primary_kernel(rtgpu_camera cam, rtgpu_render_settings st, int sampleIndex,
+                                                               float* __restrict__ ro, float* __restrict__ rd)
+{
+    const int tw = st.x_end - st.x_start, th = st.y_end - st.y_start;
+    const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+    if (k >= (uint32_t)(tw * th)) return;
+    const int x = st.x_start + (int)(k % (uint32_t)tw), y = st.y_start + (int)(k / (uint32_t)tw);
+    F3 o, d;
+    camera_ray(cam, st, x, y, sampleIndex, o, d);
+    ro[3 * k] = o.x; ro[3 * k + 1] = o.y; ro[3 * k + 2] = o.z;
+    rd[3 * k] = d.x; rd[3 * k + 1] = d.y; rd[3 * k + 2] = d.z;
+}
+
+hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const float* dD, uint64_t n,
+                                rtgpu_hit* dHits, uint32_t* dCounts, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block(64);
+    if (sv.singleMesh) {
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+    } else {
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<true, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<true, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_trace_any(const SceneView& sv, const float* dO, const float* dD, const float* dTmax,
+                            uint64_t n, uint8_t* dOcc, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    const uint64_t blocks = (n + 63) / 64;
+    if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    dim3 grid((unsigned)blocks), block(64);
+    if (sv.singleMesh) hipLaunchKernelGGL((trace_any_kernel<false>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
+    else hipLaunchKernelGGL((trace_any_kernel<true>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
+    return hipGetLastError();
+}
+
+hipError_t launch_generate_primary(const rtgpu_camera& cam, const rtgpu_render_settings& st, int32_t sampleIndex,
+                                   float* dO, float* dD, hipStream_t stream)
+{
+    const int64_t n = (int64_t)(st.x_end - st.x_start) * (st.y_end - st.y_start);
+    if (n <= 0) return hipSuccess;
+    dim3 grid((unsigned)((n + 255) / 256)), block(256);
+    hipLaunchKernelGGL(generate_primary_kernel, grid, block, 0, stream, cam, st, (int)sampleIndex, dO, dD);
+    return hipGetLastError();
+}
+
+} // namespace rt

@@ -1,0 +1,281 @@
+// rt_trace_inl.h -- device functions of the traversal / intersection path (gfx950, wave64).
+//
+// One lane owns one ray.  The per-lane traversal stack lives in LDS, laid out
+// stack[entry][lane] so that a wave's push/pop touches 64 consecutive dwords (no bank
+// conflicts); everything else is in VGPRs.  Build with -ffp-contract=off: the triangle test
+// must round exactly like the reference's separate multiplies and subtractions.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_device.h"
+
+namespace rt {
+
+struct F3 {
+    float x, y, z;
+};
+__device__ __forceinline__ F3 f3(float x, float y, float z) { return F3{x, y, z}; }
+__device__ __forceinline__ F3 operator+(F3 a, F3 b) { return F3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a, F3 b) { return F3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ F3 operator-(F3 a) { return F3{-a.x, -a.y, -a.z}; }
+__device__ __forceinline__ F3 operator*(F3 a, float s) { return F3{a.x * s, a.y * s, a.z * s}; }
+__device__ __forceinline__ F3 operator*(float s, F3 a) { return F3{s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ F3 operator/(F3 a, float s) { return F3{a.x / s, a.y / s, a.z / s}; }
+// Eigen's unrolled 3-vector reduction: x + (y + z)
+__device__ __forceinline__ float dot3(F3 a, F3 b) { return a.x * b.x + (a.y * b.y + a.z * b.z); }
+__device__ __forceinline__ F3 cross3(F3 a, F3 b) { return F3{a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x}; }
+__device__ __forceinline__ float norm3(F3 a) { return sqrtf(dot3(a, a)); }
+__device__ __forceinline__ F3 normalized3(F3 a)
+{
+    float z = dot3(a, a);
+    if (z > 0.0f) return a / sqrtf(z);
+    return a;
+}
+
+// std::max / std::min as the reference's slab test uses them (NaN-order sensitive)
+__device__ __forceinline__ float max_ref(float a, float b) { return (a < b) ? b : a; }
+__device__ __forceinline__ float min_ref(float a, float b) { return (b < a) ? b : a; }
+
+// AABB::getIntersections (shape/AABB.h:67-121) with 1/d hoisted out of the per-box work (the
+// reference divides per box; the quotient is the same value).  Returns hit and the clamped entry.
+__device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                          F3 o, F3 inv, float& t0)
+{
+    float tx1 = (lox - o.x) * inv.x, tx2 = (hix - o.x) * inv.x;
+    float ty1 = (loy - o.y) * inv.y, ty2 = (hiy - o.y) * inv.y;
+    float tz1 = (loz - o.z) * inv.z, tz2 = (hiz - o.z) * inv.z;
+    float txmin = inv.x >= 0 ? tx1 : tx2, txmax = inv.x >= 0 ? tx2 : tx1;
+    float tymin = inv.y >= 0 ? ty1 : ty2, tymax = inv.y >= 0 ? ty2 : ty1;
+    float tzmin = inv.z >= 0 ? tz1 : tz2, tzmax = inv.z >= 0 ? tz2 : tz1;
+    float a = max_ref(max_ref(txmin, tymin), tzmin);
+    float b = min_ref(min_ref(txmax, tymax), tzmax);
+    t0 = max_ref(0.0f, a);
+    return a <= b;
+}
+
+// Triangle::intersect (math/Triangle.h:34-101) on a TriRec.  c0..c2 are the cofactors
+// (e1.y*e2.z-e1.z*e2.y), (e1.x*e2.z-e1.z*e2.x), (e1.x*e2.y-e1.y*e2.x) that both the pDet and
+// the p0Det expansion use; precomputing them performs the same fp32 operations once.
+__device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const float4 r2, F3 o, F3 d,
+                                         float& t, float& beta, float& gamma)
+{
+    const float c0 = r0.w, c1 = r1.w, c2 = r2.w;
+    float pDet = (d.x * c0 - d.y * c1) + d.z * c2;
+    if (pDet == 0.0f) return false;
+    float invDet = 1.0f / pDet;
+    float xx = r0.x - o.x, xy = r0.y - o.y, xz = r0.z - o.z;
+    float p0Det = (xx * c0 - xy * c1) + xz * c2;
+    t = p0Det * invDet;
+    if (t < 0.0f) return false;
+    // det [d; x; e2]
+    float p1Det = (d.x * (xy * r2.z - xz * r2.y) - d.y * (xx * r2.z - xz * r2.x)) + d.z * (xx * r2.y - xy * r2.x);
+    beta = p1Det * invDet;
+    if (beta < 0.0f) return false;
+    // det [d; e1; x]
+    float p2Det = (d.x * (r1.y * xz - r1.z * xy) - d.y * (r1.x * xz - r1.z * xx)) + d.z * (r1.x * xy - r1.y * xx);
+    gamma = p2Det * invDet;
+    if (gamma < 0.0f) return false;
+    if (gamma + beta > 1.0f) return false;
+    return true;
+}
+
+// Sphere::intersect (shape/Sphere.cpp:16-59): unit sphere, fp64 quadratic, and the reference's
+// largestT = min(t1, t0) (a ray starting inside the sphere misses).
+__device__ __forceinline__ bool sphere_test(F3 o, F3 dir, double& t)
+{
+    double a = dot3(dir, dir);
+    double b = 2.0 * (double)dot3(dir, o);
+    double c = (double)dot3(o, o) - 1.0;
+    double disc = b * b - 4.0 * a * c;
+    if (disc < 0) return false;
+    double dr = sqrt(disc);
+    double q = -0.5 * (b < 0 ? (b - dr) : (b + dr));
+    double t0 = q / a;
+    double t1 = c / q;
+    double smallest = fmin(t0, t1); // both operands ordered: same as std::min
+    if (smallest >= 0) { t = smallest; return true; }
+    return false;
+}
+
+// Transformation::transformInverse(Ray) (math/Transformation.h:78-93,108-113) for an affine
+// inverse: fp64 row sums in the order ((m0*x + m1*y) + m2*z) + m3*w, narrowed to fp32.
+__device__ __forceinline__ F3 xf_point_inv(const double* m, F3 p)
+{
+    double x = p.x, y = p.y, z = p.z;
+    return F3{(float)(((m[0] * x + m[1] * y) + m[2] * z) + m[3]),
+              (float)(((m[4] * x + m[5] * y) + m[6] * z) + m[7]),
+              (float)(((m[8] * x + m[9] * y) + m[10] * z) + m[11])};
+}
+__device__ __forceinline__ F3 xf_vector_inv(const double* m, F3 p)
+{
+    double x = p.x, y = p.y, z = p.z;
+    return F3{(float)(((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 0.0),
+              (float)(((m[4] * x + m[5] * y) + m[6] * z) + m[7] * 0.0),
+              (float)(((m[8] * x + m[9] * y) + m[10] * z) + m[11] * 0.0)};
+}
+
+struct TraceResult {
+    float t;          // +inf on a miss
+    uint32_t slot;    // global leaf slot of the triangle, kInvalid for spheres / miss
+    uint32_t inst;    // instance index, kInvalid on a miss
+    float beta, gamma;
+};
+
+constexpr int kSentinel = 0x7FFFFFFF;
+
+// Closest hit (ANY = false: Scene::traceRay -> BVHNode::traceRay, shape/bvh/BVHNode.h:306-397)
+// or any hit within tmax (ANY = true: BVHNode::testVisibility, :399-446), through the top-level
+// tree (INSTANCED) and the mesh trees.
+//
+// Result definition (tree independent): the primitive with the smallest t; equal t -> the
+// smaller (instance, triangle index).  The reference's result for equal t depends on its
+// (unstable-sort built) tree; with unequal t both agree because boxes are conservative.  A child
+// is entered when its box is hit and its entry distance <= the best t so far.  An instance is
+// tested when the ray hits the instance's own world box (the reference tests every instance of
+// a top-level leaf whose merged box is hit).
+template <bool INSTANCED, bool ANY, bool COUNT>
+__device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 wd, float tmax,
+                                                 int (*stack)[64], const int lane, uint32_t& nBoxes, uint32_t& nTris)
+{
+    TraceResult best;
+    best.t = ANY ? tmax : INFINITY;
+    best.slot = kInvalid;
+    best.inst = kInvalid; // kInvalid = nothing found yet
+    best.beta = 0.0f;
+    best.gamma = 0.0f;
+
+    F3 o = wo, d = wd;
+    uint32_t nodeBase, triBase = 0, curInst = 0;
+    int cur;
+    int sp = 0;
+    bool inMesh;
+
+    if (INSTANCED) {
+        nodeBase = sv.topRoot;
+        // a single instance is the root leaf: entered without any box test, like the reference's root
+        cur = sv.nInst > 1 ? 0 : ~0;
+        inMesh = false;
+    } else {
+        const DevInstance& in = sv.inst[0];
+        o = xf_point_inv(in.inv, wo);
+        d = xf_vector_inv(in.inv, wd);
+        nodeBase = in.root;
+        triBase = in.triBase;
+        cur = 0;
+        inMesh = true;
+    }
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+    const F3 winv = inv;
+
+    // Pops the next pending subtree; leaves a mesh tree when its sentinel surfaces.  False = done.
+    auto pop = [&]() -> bool {
+        for (;;) {
+            if (sp == 0) return false;
+            cur = stack[--sp][lane];
+            if (INSTANCED && cur == kSentinel) {
+                inMesh = false;
+                o = wo; d = wd; inv = winv;
+                nodeBase = sv.topRoot;
+                continue;
+            }
+            return true;
+        }
+    };
+
+    bool alive = true;
+    while (alive) {
+        // ---- inner nodes: one 64-byte record holds both child boxes -----------------------
+        while (cur >= 0) {
+            const float4* np = sv.nodes + ((size_t)(nodeBase + (uint32_t)cur) << 2);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) nBoxes += 2;
+            float t0a, t0b;
+            bool ha = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, t0a);
+            bool hb = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, t0b);
+            ha = ha && t0a <= best.t;
+            hb = hb && t0b <= best.t;
+            const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+            if (ha && hb) {
+                const bool aFirst = t0a <= t0b;
+                cur = aFirst ? ca : cb;
+                stack[sp][lane] = aFirst ? cb : ca;
+                ++sp;
+            } else if (ha) {
+                cur = ca;
+            } else if (hb) {
+                cur = cb;
+            } else if (!pop()) {
+                alive = false;
+                break;
+            }
+        }
+        if (!alive) break;
+        // ---- leaf -------------------------------------------------------------------------
+        const uint32_t leaf = (uint32_t)(~cur);
+        const uint32_t first = leaf >> 4, count = (leaf & 15u) + 1u;
+        if (INSTANCED && !inMesh) {
+            // top-level leaf = one instance (InstancedModelList::traceRay, shape/list/InstancedModelList.cpp:99-138)
+            curInst = sv.instOrder[first];
+            const DevInstance& in = sv.inst[curInst];
+            o = xf_point_inv(in.inv, wo);
+            d = xf_vector_inv(in.inv, wd);
+            if (in.shape < 0) {
+                double ts;
+                if (COUNT) nTris += 1;
+                if (sphere_test(o, d, ts)) {
+                    if (ANY) {
+                        if (ts <= (double)tmax) { best.inst = curInst; return best; }
+                    } else {
+                        const float tf = (float)ts;
+                        if (best.inst == kInvalid || tf < best.t || (tf == best.t && curInst < best.inst)) {
+                            best.t = tf; best.slot = kInvalid; best.inst = curInst; best.beta = 0.0f; best.gamma = 0.0f;
+                        }
+                    }
+                }
+                o = wo; d = wd;
+                if (!pop()) break;
+                continue;
+            }
+            inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+            nodeBase = in.root;
+            triBase = in.triBase;
+            inMesh = true;
+            stack[sp][lane] = kSentinel;
+            ++sp;
+            cur = 0;
+            continue;
+        }
+        // triangle leaf (TriangleMesh::intersect / testVisibility, shape/TriangleMesh.cpp:99-175)
+        for (uint32_t k = 0; k < count; ++k) {
+            const uint32_t slot = triBase + first + k;
+            const float4* tp = sv.tris + (size_t)slot * 3;
+            const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+            float t, be, ga;
+            if (COUNT) nTris += 1;
+            if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
+                const uint32_t ci = INSTANCED ? curInst : 0u;
+                if (ANY) {
+                    if (t <= tmax) {
+                        best.slot = slot; best.inst = ci; best.beta = be; best.gamma = ga;
+                        return best;
+                    }
+                } else {
+                    bool better = best.inst == kInvalid || t < best.t;
+                    if (!better && t == best.t) {
+                        // equal t: the smaller (instance, caller's triangle index) wins
+                        if (ci < best.inst) better = true;
+                        else if (ci == best.inst && best.slot != kInvalid && sv.triIds[slot] < sv.triIds[best.slot]) better = true;
+                    }
+                    if (better) {
+                        best.t = t; best.slot = slot; best.inst = ci; best.beta = be; best.gamma = ga;
+                    }
+                }
+            }
+        }
+        if (!pop()) break;
+    }
+    if (best.inst == kInvalid) best.t = INFINITY;
+    return best;
+}
+
+} // namespace rt

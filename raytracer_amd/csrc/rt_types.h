@@ -1,0 +1,58 @@
+// rt_types.h -- layouts shared by the host builder, the C-ABI layer and the gfx950 kernels.
+//
+// HBM layout of a scene (all arrays hipMalloc'ed once per scene, read-only while tracing):
+//
+//   nodes  : Node64[]  every tree (one per mesh + the top-level tree over instances)
+//            concatenated, each tree in depth-first order.  A Node64 is one INNER node and
+//            carries the boxes of BOTH children (the reference also tests both child boxes at
+//            the parent, shape/bvh/BVHNode.h:316-320), so a traversal step is one 64-byte fetch
+//            (4 x dwordx4 from one aligned 64-B block).  Leaves have no record of their own:
+//            a child reference < 0 encodes (first primitive, count).
+//   tris   : TriRec[]  48 bytes per triangle, in leaf order per mesh: vertex a, edges
+//            e1 = a-b, e2 = a-c (the same fp32 subtractions Triangle::intersect performs per
+//            test, math/Triangle.h:38-39) and the three cofactors of rows (e1,e2) shared by the
+//            pDet and p0Det determinants.  Three aligned dwordx4 loads per test.
+//   triIds : uint32[]  leaf slot -> the caller's triangle index (the reference's
+//            permutation[triangleIndex], shape/TriangleMesh.cpp:33-36, 239-268).
+//   inst   : DevInstance[] inverse transform rows in fp64 (math/Transformation.h:78-93), tree root,
+//            triangle base, material, plus the fp32 data the shade stage needs.
+#pragma once
+#include <stdint.h>
+
+namespace rt {
+
+constexpr int kStackDepth = 32;      // per-lane traversal stack entries (LDS)
+constexpr int kMaxTreeDepth = 30;    // builder guarantee per tree (top tree + mesh tree share the stack)
+constexpr int kMaxLeafHard = 16;     // leaf size field is 4 bits
+constexpr uint32_t kInvalid = 0xFFFFFFFFu;
+
+struct Node64 {
+    float lo0[3], hi0[3];
+    float lo1[3], hi1[3];
+    int32_t c0, c1;      // >= 0: inner node index (relative to the tree's first node); < 0: leaf ~c = first << 4 | (count-1)
+    uint32_t axis;       // split axis (diagnostics)
+    uint32_t pad;
+};
+static_assert(sizeof(Node64) == 64, "Node64 must be one 64-byte block");
+
+struct TriRec {
+    float ax, ay, az, c0;
+    float e1x, e1y, e1z, c1;
+    float e2x, e2y, e2z, c2;
+};
+static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 4) | (count - 1)); }
+
+struct DevInstance {
+    double inv[12];      // rows 0..2 of the world->object 4x4 (row 3 must be 0 0 0 1)
+    uint32_t root;       // first node of the mesh tree (index into nodes), unused for spheres
+    uint32_t triBase;    // first TriRec of the mesh
+    int32_t shape;       // mesh index or -1 (sphere)
+    uint32_t material;
+    float wlo[3], whi[3]; // world AABB (InstancedModelList::getAABB)
+    uint32_t meshVertBase; // first vertex-normal triple record of the mesh (shade stage)
+    uint32_t pad;
+};
+
+} // namespace rt
