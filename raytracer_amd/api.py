@@ -43,6 +43,14 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise RtgpuError(f"{LIB_PATH} is missing: build it with `make -C raytracer_amd/csrc` "
                          "(there is no CPU fallback for the ray-tracing path)")
+    # PyTorch wheels bundle their own libamdhip64/libhsa-runtime64.  Two HIP runtimes in one process
+    # do not both see the GPU, so when torch is installed it is imported first and librtgpu.so
+    # binds to the runtime torch brought (same SONAME); without torch the system ROCm one is used.
+    if os.environ.get("RTGPU_SKIP_TORCH_PRELOAD") != "1":
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
     L = C.CDLL(LIB_PATH)
     fp, u32p, u8p, vp = abi.c_float_p, abi.c_u32_p, abi.c_u8_p, C.c_void_p
     L.rtgpu_last_error.restype = C.c_char_p

@@ -2,6 +2,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <chrono>
 #include <cmath>
 #include <cstring>
@@ -13,6 +14,7 @@
 #include "bvh_build.h"
 #include "rt_device.h"
 #include "rt_scene.h"
+#include "top_tree_ref.h"
 
 namespace {
 
@@ -231,9 +233,45 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
             di.whi[a] = instBoxes[i].hi[a] = whi[a];
         }
     }
+    bool hasSphere = false;
+    for (uint32_t i = 0; i < nInst; ++i) hasSphere = hasSphere || desc->instances[i].shape < 0;
+    const bool refTop = hasSphere && nInst > 1;
     BuiltTree top;
+    RefTopTree rtop;
     int meshDepthBudget = kStackDepth - 1;
-    if (nInst > 1) {
+    if (refTop) {
+        // sort key of InstancedModelList::sortByCentroid (:48-58): transform(shape centroid), with
+        // TriangleMesh::getCentroid (shape/TriangleMesh.cpp:57-76, 205-212) for meshes
+        std::vector<std::array<float, 3>> meshCen(desc->n_meshes);
+        for (uint32_t m = 0; m < desc->n_meshes; ++m) {
+            const rtgpu_mesh_desc& md = desc->meshes[m];
+            const float cnt = (float)md.n_triangles;
+            float c[3] = {0, 0, 0};
+            for (uint32_t t = 0; t < md.n_triangles; ++t) {
+                const float* p1 = md.vertices + 3 * (size_t)md.indices[3 * (size_t)t];
+                const float* p2 = md.vertices + 3 * (size_t)md.indices[3 * (size_t)t + 1];
+                const float* p3 = md.vertices + 3 * (size_t)md.indices[3 * (size_t)t + 2];
+                for (int a = 0; a < 3; ++a) {
+                    const float tc = ((p1[a] + p2[a]) + p3[a]) / 3.0f;
+                    c[a] = t == 0 ? tc / cnt : c[a] + tc / cnt;
+                }
+            }
+            meshCen[m] = {c[0], c[1], c[2]};
+        }
+        std::vector<std::array<float, 3>> keys(nInst);
+        for (uint32_t i = 0; i < nInst; ++i) {
+            const rtgpu_instance_desc& id = desc->instances[i];
+            const float zero[3] = {0, 0, 0};
+            float k[3];
+            xf_point(id.transform, id.shape >= 0 ? meshCen[id.shape].data() : zero, k);
+            keys[i] = {k[0], k[1], k[2]};
+        }
+        rtop = build_top_tree_reference(instBoxes.data(), reinterpret_cast<const float(*)[3]>(keys.data()), nInst);
+        if (rtop.maxDepth > (uint32_t)rt::kTopFramesHost) return fail(RTGPU_ERR_LIMIT, "top-level tree deeper than 48 levels");
+        if (rtop.maxLeaf > kMaxTopLeaf) return fail(RTGPU_ERR_LIMIT, "top-level leaf with more than 256 instances");
+        if (nInst >= (1u << 23)) return fail(RTGPU_ERR_LIMIT, "more than 2^23 instances in a scene with spheres");
+        meshDepthBudget = kStackDepth - 1;
+    } else if (nInst > 1) {
         BuildParams tp;
         tp.maxLeaf = 1;
         tp.maxLeafHard = 1;
@@ -303,11 +341,15 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     const uint32_t topRoot = (uint32_t)nodes.size();
     std::vector<uint32_t> instOrder(nInst);
     for (uint32_t i = 0; i < nInst; ++i) instOrder[i] = i;
-    if (nInst > 1) {
+    if (refTop) {
+        nodes.insert(nodes.end(), rtop.nodes.begin(), rtop.nodes.end());
+        instOrder = rtop.order;
+        info.max_depth = rtop.maxDepth + info.max_depth;
+    } else if (nInst > 1) {
         nodes.insert(nodes.end(), top.nodes.begin(), top.nodes.end());
         instOrder = top.order;
         info.n_leaves += top.leafCount;
-        info.max_depth = std::max(info.max_depth, top.maxDepth + 1 + info.max_depth);
+        info.max_depth = top.maxDepth + 1 + info.max_depth;
     }
     if (nodes.size() >= (1ull << 31)) return fail(RTGPU_ERR_LIMIT, "more than 2^31 tree nodes");
     info.n_nodes = nodes.size();
@@ -371,6 +413,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nInst = nInst;
     v.topRoot = topRoot;
     v.singleMesh = singleMesh ? 1u : 0u;
+    v.refTop = refTop ? 1u : 0u;
+    v.refTopRoot = (refTop && rtop.rootIsLeaf) ? encode_top_leaf(0, nInst) : 0;
     v.nMaterials = desc->n_materials;
     v.nPointLights = desc->n_point_lights;
     v.nAreaLights = desc->n_area_lights;

@@ -1,20 +1,654 @@
-// rt_integrator.hip -- wavefront path-tracing integrator (placeholder until the pipeline lands).
+// rt_integrator.hip -- the path-tracing integrator as a wavefront pipeline (gfx950).
+//
+// Restates RenderTileTask::execute / samplePath / calculatePathEnergy (renderer/Renderer.cpp:14-270)
+// over queues instead of per-pixel recursion:
+//
+//   primary : one lane per (pixel, geometry sample i): camera ray + closest hit + the area-light
+//             pre-test and the miss/environment case (Renderer.cpp:150-225)
+//   init    : one lane per path (pixel, i, material sample j): path state from the sample's hit
+//   shade   : one lane per live path vertex: material closure (Diffuse / Glossy / Emissive /
+//             ConstMix), next-event estimation, Russian roulette; emits one extension ray or one
+//             shadow ray, or ends the path
+//   shadow  : any-hit query; an unoccluded path receives its pending contribution
+//   extend  : closest-hit query for the extension rays
+//   resolve : per pixel, sums the path values in the reference's order and writes the frame buffer
+//
+// Queues hold path indices and are filled with wave-aggregated appends (one atomic per wave:
+// ballot + popcount + prefix).  Every path ends with at most one contribution (next-event
+// estimation is terminal in the reference's estimator), which is stored per path and summed by
+// `resolve` in a fixed order: the image does not depend on queue order, batch size or GPU count.
+//
+// The reference evaluates a finished path backwards (calculatePathEnergy); here the product of
+// the per-vertex factors is carried forwards as a throughput.  The factors are the same; only
+// the order of the float multiplications differs.
+//
+// Resampling (materialAA): the reference samples the path once, then re-samples it materialAA-1
+// times from the first vertex whose material has variance.  Here every (i, j) is its own path
+// from vertex 0 that shares the sample's primary hit; vertices before the first variance vertex
+// draw their random numbers with j = 0, so all j make identical decisions there -- the same
+// joint distribution as sampling that prefix once.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
+#include <cstdlib>
+#include <vector>
+
 #include "rt_scene.h"
+#include "rt_shade_inl.h"
 
 namespace rt {
 
-void area_light_derived(DevAreaLight& l)
+namespace {
+
+constexpr uint32_t ST_K_MASK = 63u;
+constexpr uint32_t ST_PASSED_VAR = 1u << 6;
+constexpr uint32_t ST_GLOSSY_PENDING = 1u << 7;
+constexpr uint32_t ST_GLOSSY_ROUGH = 1u << 8;
+constexpr uint32_t ST_RETRACE = 1u << 9;
+
+struct Pool {
+    float* ro;            // 3 per path: origin of the ray that produced the current hit / of the pending ray
+    float* rd;            // 3 per path
+    float* hitT;
+    uint32_t* hitSlot;
+    uint32_t* hitInst;
+    float* hitBeta;
+    float* hitGamma;
+    float* thr;           // 3 per path: throughput
+    float* contrib;       // 3 per path: pending contribution (shadow ray) or the glossy vertex's hit point
+    float* tmax;          // shadow-ray limit
+    uint32_t* state;
+    float* result;        // 3 per path
+    // per sample (pixel, i)
+    float* sRo;
+    float* sRd;
+    float* sT;
+    uint32_t* sSlot;
+    uint32_t* sInst;
+    float* sBeta;
+    float* sGamma;
+    uint8_t* sLive;       // 1: paths are spawned from this sample
+    uint8_t* sHasVar;     // 1: the sample's path reached a vertex with variance (divide by materialAA)
+    // queues
+    uint32_t* qA;
+    uint32_t* qB;
+    uint32_t* qShadow;
+    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] init queue size, [3] prefix rays repeated per material sample
+};
+
+struct Batch {
+    uint32_t pixelStart;  // first tile-local pixel index of the batch
+    uint32_t nPixels;
+};
+
+__device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, uint32_t tileIdx, int& x, int& y)
 {
-    (void)l;
+    const uint32_t tw = (uint32_t)(st.x_end - st.x_start);
+    x = st.x_start + (int)(tileIdx % tw);
+    y = st.y_start + (int)(tileIdx / tw);
+    return (uint32_t)(y * st.width + x);
 }
 
-hipError_t render_wavefront(const rtgpu_scene&, const rtgpu_camera&, const rtgpu_render_settings&, float*,
-                            rtgpu_render_stats*, hipStream_t, std::string& err)
+// Appends `value` to a queue for every lane with pred == true using one atomic per wave.
+__device__ __forceinline__ void queue_push(uint32_t* queue, uint32_t* counter, bool pred, uint32_t value)
 {
-    err = "integrator not built yet";
-    return hipErrorNotSupported;
+    const unsigned long long mask = __ballot(pred);
+    if (mask == 0ull) return;
+    const int lane = (int)(threadIdx.x & 63u);
+    const int leader = __ffsll((long long)mask) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (pred) {
+        const unsigned long long below = mask & ((1ull << lane) - 1ull);
+        queue[base + (uint32_t)__popcll(below)] = value;
+    }
+}
+
+template <bool INSTANCED>
+__device__ __forceinline__ TraceResult trace_closest_any_mode(const SceneView& sv, F3 o, F3 d, int (*stack)[64], int lane)
+{
+    uint32_t nb = 0, nt = 0;
+    if (INSTANCED && sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, stack, lane, nb, nt);
+    return trace_ray<INSTANCED, false, false>(sv, o, d, INFINITY, stack, lane, nb, nt);
+}
+
+// ---- primary ---------------------------------------------------------------------------------
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
+{
+    __shared__ int stack[kStackDepth][64];
+    const int lane = threadIdx.x;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    const uint32_t s = blockIdx.x * 64u + lane;
+    if (s >= batch.nPixels * G) return;
+    const uint32_t pl = s / G, i = s % G;
+    int x, y;
+    tile_pixel(st, batch.pixelStart + pl, x, y);
+    F3 o, d;
+    camera_ray(cam, st, x, y, (int)i, o, d);
+    const TraceResult r = trace_closest_any_mode<INSTANCED>(sv, o, d, stack, lane);
+    const bool hit = r.inst != kInvalid;
+
+    float* res0 = pool.result + (size_t)s * M * 3;
+    RGBf value = rgb(0, 0, 0);
+    bool live = hit;
+    // an area light closer than the hit (renderer/Renderer.cpp:184-204)
+    {
+        float bestT = hit ? r.t : INFINITY;
+        int light = -1;
+        for (uint32_t li = 0; li < sv.nAreaLights; ++li) {
+            float lt;
+            if (area_light_hit(sv.areaLights[li], o, d, lt) && bestT > lt) { light = (int)li; bestT = lt; }
+        }
+        if (light >= 0) {
+            value = rgb_scale_f(area_light_irradiance(sv.areaLights[light]), 1.0f / (float)2); // .divide(2)
+            live = false;
+        } else if (!hit) {
+            if (sv.hasEnv) value = rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]); // Renderer.cpp:217-225
+            live = false;
+        }
+    }
+    pool.sLive[s] = live ? 1 : 0;
+    pool.sHasVar[s] = 0;
+    if (!live) {
+        res0[0] = value.r; res0[1] = value.g; res0[2] = value.b;
+        return;
+    }
+    pool.sRo[3 * s] = o.x; pool.sRo[3 * s + 1] = o.y; pool.sRo[3 * s + 2] = o.z;
+    pool.sRd[3 * s] = d.x; pool.sRd[3 * s + 1] = d.y; pool.sRd[3 * s + 2] = d.z;
+    pool.sT[s] = r.t; pool.sSlot[s] = r.slot; pool.sInst[s] = r.inst; pool.sBeta[s] = r.beta; pool.sGamma[s] = r.gamma;
+}
+
+// ---- init ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void init_kernel(Pool pool, uint32_t nPaths, uint32_t M, uint32_t* counter)
+{
+    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
+    const bool inRange = p < nPaths;
+    bool live = false;
+    if (inRange) {
+        const uint32_t s = p / M, j = p % M;
+        live = pool.sLive[s] != 0;
+        if (live || j != 0) { pool.result[3 * (size_t)p] = 0.0f; pool.result[3 * (size_t)p + 1] = 0.0f; pool.result[3 * (size_t)p + 2] = 0.0f; }
+        if (live) {
+            for (int c = 0; c < 3; ++c) {
+                pool.ro[3 * (size_t)p + c] = pool.sRo[3 * (size_t)s + c];
+                pool.rd[3 * (size_t)p + c] = pool.sRd[3 * (size_t)s + c];
+                pool.thr[3 * (size_t)p + c] = 1.0f;
+            }
+            pool.hitT[p] = pool.sT[s]; pool.hitSlot[p] = pool.sSlot[s]; pool.hitInst[p] = pool.sInst[s];
+            pool.hitBeta[p] = pool.sBeta[s]; pool.hitGamma[p] = pool.sGamma[s];
+            pool.state[p] = 0u;
+        }
+    }
+    queue_push(pool.qA, counter, live, p);
+}
+
+// World-space shading normal of a hit: interpolated vertex normals (shape/TriangleMesh.cpp:114-120)
+// or the sphere's object-space hit point (shape/Sphere.cpp:52-53), then transformNormal + normalize
+// (shape/list/InstancedModelList.cpp:129-130, math/Transformation.h:95-99).
+__device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance& in, F3 wo, F3 wd, float t, uint32_t slot, float beta, float gamma)
+{
+    F3 objN;
+    if (slot != kInvalid) {
+        const float* vn = sv.vertNormals + (size_t)slot * 9;
+        const float alfa = 1.0f - beta - gamma;
+        const F3 na = f3(vn[0], vn[1], vn[2]), nb = f3(vn[3], vn[4], vn[5]), nc = f3(vn[6], vn[7], vn[8]);
+        objN = ((alfa * na) + (beta * nb)) + (gamma * nc);
+    } else {
+        const F3 oo = xf_point_inv(in.inv, wo), od = xf_vector_inv(in.inv, wd);
+        objN = oo + (t * od);
+    }
+    const double nx = objN.x, ny = objN.y, nz = objN.z;
+    const double* m = in.inv;
+    const F3 wn = f3((float)(((nx * m[0] + ny * m[4]) + nz * m[8]) + 0.0),
+                     (float)(((nx * m[1] + ny * m[5]) + nz * m[9]) + 0.0),
+                     (float)(((nx * m[2] + ny * m[6]) + nz * m[10]) + 0.0));
+    return normalized3(wn);
+}
+
+// ---- shade -----------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
+                                                    const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
+{
+    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    bool pushExt = false, pushShadow = false, repeated = false;
+    uint32_t p = 0;
+    if (q < nIn) {
+        p = qIn[q];
+        const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+        const int maxLen = st.max_path_length;
+        const uint32_t s = p / M, j = p % M;
+        const uint32_t pl = s / G, i = s % G;
+        int px, py;
+        const uint32_t pixel = tile_pixel(st, batch.pixelStart + pl, px, py);
+        uint32_t state = pool.state[p];
+        int k = (int)(state & ST_K_MASK);
+        F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
+        F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
+        RGBf thr = rgb(pool.thr[3 * (size_t)p], pool.thr[3 * (size_t)p + 1], pool.thr[3 * (size_t)p + 2]);
+        const float t = pool.hitT[p];
+        const uint32_t inst = pool.hitInst[p];
+        const bool hit = inst != kInvalid;
+        bool passed = (state & ST_PASSED_VAR) != 0;
+        bool done = false;
+        RGBf result = rgb(0, 0, 0);
+        bool haveResult = false;
+
+        if (state & ST_GLOSSY_PENDING) {
+            // GlossyMaterial::sampleTransport after its own traceRay (material/GlossyMaterial.cpp:126-178),
+            // then the Russian roulette of samplePath for that vertex (renderer/Renderer.cpp:52)
+            const bool rough = (state & ST_GLOSSY_ROUGH) != 0;
+            int lightIdx = -1;
+            if (rough) {
+                for (uint32_t li = 0; li < sv.nAreaLights; ++li) {
+                    float lt;
+                    if (area_light_hit(sv.areaLights[li], o, d, lt) && (!hit || t > lt)) { lightIdx = (int)li; break; }
+                }
+            } else {
+                double bestT = hit ? (double)t : 1E99;
+                for (uint32_t li = 0; li < sv.nAreaLights; ++li) {
+                    float lt;
+                    if (area_light_hit(sv.areaLights[li], o, d, lt) && bestT > (double)lt) { lightIdx = (int)li; bestT = lt; }
+                }
+            }
+            if (lightIdx >= 0) {
+                done = true;
+                if (!rough && k + 1 != maxLen) { // mirror: the light's irradiance / 2 (GlossyMaterial.cpp:198-203)
+                    result = rgb_mul(thr, rgb_scale_f(area_light_irradiance(sv.areaLights[lightIdx]), 1.0f / (float)2));
+                    haveResult = true;
+                }
+            } else {
+                const uint32_t rs = i * M + (passed ? j : 0u);
+                const bool terminated = (k + 1 == maxLen) || rand_unit(st.seed, pixel, rs, (uint32_t)k, DIM_RR) < 0.2f;
+                if (terminated) {
+                    done = true;
+                } else {
+                    const float f = (rough ? 2.0f : 1.0f) * (1.0f / (1.0f - 0.2f));
+                    thr = rgb_scale_f(thr, f);
+                    state &= ~(ST_GLOSSY_PENDING | ST_GLOSSY_ROUGH);
+                    if (!hit) {
+                        // ctx.nextHit is empty: samplePath traces again from hitpoint + dir * 1e-4 (Renderer.cpp:57-61)
+                        const F3 hp = f3(pool.contrib[3 * (size_t)p], pool.contrib[3 * (size_t)p + 1], pool.contrib[3 * (size_t)p + 2]);
+                        o = hp + (d * 0.0001f);
+                        pool.ro[3 * (size_t)p] = o.x; pool.ro[3 * (size_t)p + 1] = o.y; pool.ro[3 * (size_t)p + 2] = o.z;
+                        pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
+                        pool.state[p] = state | ST_RETRACE;
+                        pushExt = true;
+                        done = true; // nothing more for this vertex now
+                    } else {
+                        k += 1;
+                        state = (state & ~ST_K_MASK) | (uint32_t)k;
+                    }
+                }
+            }
+        } else if (state & ST_RETRACE) {
+            state &= ~ST_RETRACE;
+            if (!hit) {
+                done = true;
+                if (sv.hasEnv) { result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2])); haveResult = true; }
+            } else {
+                k += 1;
+                state = (state & ~ST_K_MASK) | (uint32_t)k;
+            }
+        } else if (k > 0 && !hit) {
+            // the extension ray left the scene: the path ends at the previous vertex and collects
+            // the environment along its transport direction (renderer/Renderer.cpp:73-76, 94-98)
+            done = true;
+            if (sv.hasEnv) { result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2])); haveResult = true; }
+        }
+
+        if (!done) {
+            // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
+            const DevInstance& in = sv.inst[inst];
+            const uint32_t slot = pool.hitSlot[p];
+            const float beta = pool.hitBeta[p], gamma = pool.hitGamma[p];
+            uint32_t mi = in.material;
+            if (slot != kInvalid && sv.triMaterial) {
+                const uint32_t tm = sv.triMaterial[slot];
+                if (tm != kInvalid) mi = tm;
+            }
+            const bool curVar = mat_has_variance(sv, mi);
+            const bool isFirstVar = curVar && !passed;
+            const int sampleCount = isFirstVar ? (int)M : 1;
+            const int sampleI = isFirstVar ? (int)j : 0;
+            passed = passed || curVar;
+            if (passed) state |= ST_PASSED_VAR;
+            if (curVar && j == 0) pool.sHasVar[s] = 1;
+            const uint32_t rs = i * M + (passed ? j : 0u);
+            const uint32_t vk = (uint32_t)k;
+            // MixMaterial::sampleTransport (material/MixMaterial.cpp:9-26)
+            for (uint32_t level = 0; level < 4 && sv.materials[mi].type == RTGPU_MAT_CONSTMIX; ++level) {
+                const DevMaterial& mm = sv.materials[mi];
+                const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mm.mixFactor;
+                mi = choseFirst ? mm.first : mm.second;
+            }
+            const DevMaterial& mat = sv.materials[mi];
+            const RGBf color = rgb(mat.color[0], mat.color[1], mat.color[2]);
+            const F3 hitpoint = o + (d * t); // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
+            const bool lastVertex = (k + 1 == maxLen); // such a path is "terminated" and contributes nothing
+
+            if (mat.type == RTGPU_MAT_EMISSIVE) {
+                // EmissiveMaterial (material/EmissiveMaterial.cpp:5-22)
+                done = true;
+                if (!lastVertex) { result = rgb_mul(thr, rgb_scale_d(color, mat.intensity)); haveResult = true; }
+            } else if (lastVertex) {
+                done = true;
+            } else {
+                const F3 normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
+                if (mat.type == RTGPU_MAT_DIFFUSE) {
+                    // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
+                    const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;
+                    if (useNEE) {
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
+                        done = true;
+                        if (ns.valid) {
+                            const double angle = fmaxf(0.0f, dot3(normal, ns.dir));
+                            const RGBf direct = rgb_scale_d(ns.radiance, angle);
+                            const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensity / RT_PI), 2.0f);
+                            const RGBf c = rgb_mul(thr, rgb_mul(color, value));
+                            const F3 so = hitpoint + (ns.dir * 0.0001f);
+                            pool.ro[3 * (size_t)p] = so.x; pool.ro[3 * (size_t)p + 1] = so.y; pool.ro[3 * (size_t)p + 2] = so.z;
+                            pool.rd[3 * (size_t)p] = ns.dir.x; pool.rd[3 * (size_t)p + 1] = ns.dir.y; pool.rd[3 * (size_t)p + 2] = ns.dir.z;
+                            pool.tmax[p] = ns.tmax;
+                            pool.contrib[3 * (size_t)p] = c.r; pool.contrib[3 * (size_t)p + 1] = c.g; pool.contrib[3 * (size_t)p + 2] = c.b;
+                            pushShadow = true;
+                        }
+                    } else {
+                        const Basis3 basis = basis_from(normal);
+                        float sx, sy;
+                        stratified_square((int)sqrt((double)sampleCount), (float)sampleI,
+                                          rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_X), rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_Y), sx, sy);
+                        const F3 l = cosine_hemisphere(sx, sy);
+                        const F3 dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
+                        const bool terminated = rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.1f;
+                        if (terminated) {
+                            done = true;
+                        } else {
+                            const double angle = fmaxf(0.0f, dot3(normal, dir));
+                            const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
+                            const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
+                            thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
+                            const F3 eo = hitpoint + (dir * 0.0001f);
+                            pool.ro[3 * (size_t)p] = eo.x; pool.ro[3 * (size_t)p + 1] = eo.y; pool.ro[3 * (size_t)p + 2] = eo.z;
+                            pool.rd[3 * (size_t)p] = dir.x; pool.rd[3 * (size_t)p + 1] = dir.y; pool.rd[3 * (size_t)p + 2] = dir.z;
+                            pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
+                            state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
+                            pool.state[p] = state;
+                            pushExt = true;
+                            done = true;
+                        }
+                    }
+                } else { // RTGPU_MAT_GLOSSY: GlossyMaterial::sampleTransport / bsdf (material/GlossyMaterial.cpp:68-207)
+                    const float roughness = mat.roughness;
+                    const bool neeEnabled = roughness > 0;
+                    const bool useNEE = neeEnabled && rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5;
+                    if (useNEE) {
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
+                        done = true;
+                        if (ns.valid) {
+                            const F3 micro = normalized3((-d) + ns.dir);
+                            const double angle = fmaxf(0.0f, dot3(micro, ns.dir));
+                            const float f = ggx_brdf(roughness, -d, ns.dir, normal, micro);
+                            const RGBf neeRadiance = rgb_scale_d(rgb_scale_d(ns.radiance, angle), f);
+                            const RGBf c = rgb_mul(thr, rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color));
+                            const F3 so = hitpoint + (ns.dir * 0.0001f);
+                            pool.ro[3 * (size_t)p] = so.x; pool.ro[3 * (size_t)p + 1] = so.y; pool.ro[3 * (size_t)p + 2] = so.z;
+                            pool.rd[3 * (size_t)p] = ns.dir.x; pool.rd[3 * (size_t)p + 1] = ns.dir.y; pool.rd[3 * (size_t)p + 2] = ns.dir.z;
+                            pool.tmax[p] = ns.tmax;
+                            pool.contrib[3 * (size_t)p] = c.r; pool.contrib[3 * (size_t)p + 1] = c.g; pool.contrib[3 * (size_t)p + 2] = c.b;
+                            pushShadow = true;
+                        }
+                    } else {
+                        float sx, sy;
+                        stratified_square(sampleCount, (float)sampleI,
+                                          rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_X), rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_Y), sx, sy);
+                        const F3 micro = normalized3(vndf_sample(normal, -d, roughness, sx, sy));
+                        // getPerfectReflectionDir (GlossyMaterial.cpp:22-25): the double factor narrows to float
+                        const F3 sampleDir = d + ((float)(2.0 * (double)dot3(micro, -d)) * micro);
+                        done = true;
+                        if (!(dot3(sampleDir, normal) < 0)) {
+                            thr = rgb_mul(thr, color);
+                            const F3 eo = hitpoint + (sampleDir * 0.001f);
+                            pool.ro[3 * (size_t)p] = eo.x; pool.ro[3 * (size_t)p + 1] = eo.y; pool.ro[3 * (size_t)p + 2] = eo.z;
+                            pool.rd[3 * (size_t)p] = sampleDir.x; pool.rd[3 * (size_t)p + 1] = sampleDir.y; pool.rd[3 * (size_t)p + 2] = sampleDir.z;
+                            pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
+                            pool.contrib[3 * (size_t)p] = hitpoint.x; pool.contrib[3 * (size_t)p + 1] = hitpoint.y; pool.contrib[3 * (size_t)p + 2] = hitpoint.z;
+                            state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
+                            pool.state[p] = state;
+                            pushExt = true;
+                        }
+                    }
+                }
+            }
+        }
+        repeated = j != 0 && (pool.state[p] & ST_PASSED_VAR) == 0;
+        if (haveResult) {
+            pool.result[3 * (size_t)p] = result.r; pool.result[3 * (size_t)p + 1] = result.g; pool.result[3 * (size_t)p + 2] = result.b;
+        }
+    }
+    queue_push(qExt, pool.counters + 0, pushExt, p);
+    queue_push(pool.qShadow, pool.counters + 1, pushShadow, p);
+    // Extension rays of vertices before the first variance vertex are identical for every material
+    // sample j (the reference traces them once per geometry sample): count the repeats so that
+    // the ray statistics only contain distinct rays.
+    const unsigned long long rep = __ballot(pushExt && repeated);
+    if (rep != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)rep) - 1)) atomicAdd(pool.counters + 3, (uint32_t)__popcll(rep));
+}
+
+// ---- shadow / connect --------------------------------------------------------------------------
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uint32_t n)
+{
+    __shared__ int stack[kStackDepth][64];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x * 64u + lane;
+    if (q >= n) return;
+    const uint32_t p = pool.qShadow[q];
+    const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
+    const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
+    const float tmax = pool.tmax[p];
+    bool occluded;
+    if (INSTANCED && sv.refTop) {
+        occluded = trace_ray_reftop_any(sv, o, d, tmax, stack, lane);
+    } else {
+        uint32_t nb = 0, nt = 0;
+        occluded = trace_ray<INSTANCED, true, false>(sv, o, d, tmax, stack, lane, nb, nt).inst != kInvalid;
+    }
+    if (!occluded) {
+        pool.result[3 * (size_t)p] = pool.contrib[3 * (size_t)p];
+        pool.result[3 * (size_t)p + 1] = pool.contrib[3 * (size_t)p + 1];
+        pool.result[3 * (size_t)p + 2] = pool.contrib[3 * (size_t)p + 2];
+    }
+}
+
+// ---- extend --------------------------------------------------------------------------------------
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ queue, uint32_t n)
+{
+    __shared__ int stack[kStackDepth][64];
+    const int lane = threadIdx.x;
+    const uint32_t q = blockIdx.x * 64u + lane;
+    if (q >= n) return;
+    const uint32_t p = queue[q];
+    const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
+    const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
+    const TraceResult r = trace_closest_any_mode<INSTANCED>(sv, o, d, stack, lane);
+    pool.hitT[p] = r.t; pool.hitSlot[p] = r.slot; pool.hitInst[p] = r.inst; pool.hitBeta[p] = r.beta; pool.hitGamma[p] = r.gamma;
+}
+
+// ---- resolve ---------------------------------------------------------------------------------------
+// pixelValue accumulation of renderer/Renderer.cpp:236-263: per geometry sample the material
+// samples are added in order and divided by materialAA (only when a variance vertex exists),
+// the sample values are added in order and divided by geometryAA.
+__global__ __launch_bounds__(256) void resolve_kernel(Pool pool, rtgpu_render_settings st, Batch batch, float* __restrict__ fb)
+{
+    const uint32_t pl = blockIdx.x * 256u + threadIdx.x;
+    if (pl >= batch.nPixels) return;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    int x, y;
+    const uint32_t pixel = tile_pixel(st, batch.pixelStart + pl, x, y);
+    RGBf px = rgb(0, 0, 0);
+    for (uint32_t i = 0; i < G; ++i) {
+        const uint32_t s = pl * G + i;
+        const float* r = pool.result + (size_t)s * M * 3;
+        RGBf m = rgb(r[0], r[1], r[2]);
+        if (pool.sLive[s] && pool.sHasVar[s]) {
+            for (uint32_t j = 1; j < M; ++j) { m.r += r[3 * j]; m.g += r[3 * j + 1]; m.b += r[3 * j + 2]; }
+            m = rgb_scale_f(m, 1.0f / (float)M);
+        }
+        px.r += m.r; px.g += m.g; px.b += m.b;
+    }
+    px = rgb_scale_f(px, 1.0f / (float)G);
+    fb[3 * (size_t)pixel] = px.r; fb[3 * (size_t)pixel + 1] = px.g; fb[3 * (size_t)pixel + 2] = px.b;
+}
+
+struct Workspace {
+    std::vector<void*> ptrs;
+    hipError_t err = hipSuccess;
+    template <typename T>
+    T* alloc(size_t n)
+    {
+        if (err != hipSuccess) return nullptr;
+        void* p = nullptr;
+        err = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
+        if (err == hipSuccess) ptrs.push_back(p);
+        return (T*)p;
+    }
+    ~Workspace()
+    {
+        for (void* p : ptrs) (void)hipFree(p);
+    }
+};
+
+} // namespace
+
+void area_light_derived(DevAreaLight& l)
+{
+    // AreaLight::getNormal (light/AreaLight.cpp:43-48) and Triangle::getSurfaceArea (math/Triangle.h:7-18), fp32
+    auto sub = [](const float* a, const float* b, float* r) { for (int k = 0; k < 3; ++k) r[k] = a[k] - b[k]; };
+    auto dot = [](const float* a, const float* b) { return a[0] * b[0] + (a[1] * b[1] + a[2] * b[2]); };
+    float ab[3], ac[3];
+    sub(l.b, l.a, ab);
+    sub(l.c, l.a, ac);
+    float n[3] = {ab[1] * ac[2] - ab[2] * ac[1], ab[2] * ac[0] - ab[0] * ac[2], ab[0] * ac[1] - ab[1] * ac[0]};
+    const float z = dot(n, n);
+    if (z > 0) { const float len = std::sqrt(z); for (float& c : n) c /= len; }
+    for (int k = 0; k < 3; ++k) l.normal[k] = n[k];
+    const float v1Length = std::sqrt(dot(ab, ab));
+    float v1n[3] = {ab[0] / v1Length, ab[1] / v1Length, ab[2] / v1Length};
+    const float pr = dot(ac, v1n);
+    float h[3] = {ac[0] - v1n[0] * pr, ac[1] - v1n[1] * pr, ac[2] - v1n[2] * pr};
+    const float height = std::sqrt(dot(h, h));
+    l.area = v1Length * height / 2.0f;
+}
+
+hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st,
+                            float* dRgb, rtgpu_render_stats* stats, hipStream_t stream, std::string& err)
+{
+    const SceneView& sv = scene.view;
+    const uint32_t tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
+    const uint64_t nPixelsTotal = (uint64_t)tw * th;
+    if (stats) *stats = rtgpu_render_stats{};
+    if (nPixelsTotal == 0) return hipSuccess;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    const uint64_t pathsPerPixel = (uint64_t)G * M;
+
+    uint64_t capPaths = 1ull << 23; // paths resident per batch (about 100 bytes of state each)
+    if (const char* e = std::getenv("RTGPU_BATCH_PATHS")) {
+        const long long v = std::atoll(e);
+        if (v > 0) capPaths = (uint64_t)v;
+    }
+    uint64_t pixelsPerBatch = std::max<uint64_t>(1, capPaths / pathsPerPixel);
+    pixelsPerBatch = std::min<uint64_t>(pixelsPerBatch, nPixelsTotal);
+    const uint64_t P = pixelsPerBatch * pathsPerPixel;
+    const uint64_t S = pixelsPerBatch * G;
+    if (P >= (1ull << 31)) { err = "geometry_aa * material_aa too large for one batch"; return hipErrorInvalidValue; }
+
+    Workspace ws;
+    Pool pool{};
+    pool.ro = ws.alloc<float>(3 * P); pool.rd = ws.alloc<float>(3 * P);
+    pool.hitT = ws.alloc<float>(P); pool.hitSlot = ws.alloc<uint32_t>(P); pool.hitInst = ws.alloc<uint32_t>(P);
+    pool.hitBeta = ws.alloc<float>(P); pool.hitGamma = ws.alloc<float>(P);
+    pool.thr = ws.alloc<float>(3 * P); pool.contrib = ws.alloc<float>(3 * P); pool.tmax = ws.alloc<float>(P);
+    pool.state = ws.alloc<uint32_t>(P); pool.result = ws.alloc<float>(3 * P);
+    pool.sRo = ws.alloc<float>(3 * S); pool.sRd = ws.alloc<float>(3 * S); pool.sT = ws.alloc<float>(S);
+    pool.sSlot = ws.alloc<uint32_t>(S); pool.sInst = ws.alloc<uint32_t>(S); pool.sBeta = ws.alloc<float>(S); pool.sGamma = ws.alloc<float>(S);
+    pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
+    pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
+    pool.counters = ws.alloc<uint32_t>(4);
+    if (ws.err != hipSuccess) { err = std::string("render workspace: ") + hipGetErrorString(ws.err); return ws.err; }
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    hipError_t e;
+#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); goto fail; } } while (0)
+    RT_TRY(hipEventCreate(&ev0));
+    RT_TRY(hipEventCreate(&ev1));
+    RT_TRY(hipEventRecord(ev0, stream));
+    {
+        uint64_t primary = 0, extension = 0, shadow = 0;
+        const bool single = sv.singleMesh != 0;
+        for (uint64_t start = 0; start < nPixelsTotal; start += pixelsPerBatch) {
+            Batch batch;
+            batch.pixelStart = (uint32_t)start;
+            batch.nPixels = (uint32_t)std::min<uint64_t>(pixelsPerBatch, nPixelsTotal - start);
+            const uint32_t nS = batch.nPixels * G;
+            const uint32_t nP = nS * M;
+            RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
+            if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
+            else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
+            hipLaunchKernelGGL(init_kernel, dim3((nP + 255) / 256), dim3(256), 0, stream, pool, nP, M, pool.counters + 2);
+            primary += nS;
+            uint32_t h[4];
+            RT_TRY(hipMemcpyAsync(h, pool.counters, sizeof(h), hipMemcpyDeviceToHost, stream));
+            RT_TRY(hipStreamSynchronize(stream));
+            uint32_t nActive = h[2];
+            uint32_t* qIn = pool.qA;
+            uint32_t* qOut = pool.qB;
+            // at most one glossy re-trace step per vertex on top of the vertex steps
+            for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
+                RT_TRY(hipMemsetAsync(pool.counters, 0, 2 * sizeof(uint32_t), stream));
+                RT_TRY(hipMemsetAsync(pool.counters + 3, 0, sizeof(uint32_t), stream));
+                hipLaunchKernelGGL(shade_kernel, dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
+                RT_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
+                RT_TRY(hipStreamSynchronize(stream));
+                const uint32_t nExt = h[0], nShadow = h[1];
+                if (nShadow) {
+                    if (single) hipLaunchKernelGGL((shadow_kernel<false>), dim3((nShadow + 63) / 64), dim3(64), 0, stream, sv, pool, nShadow);
+                    else hipLaunchKernelGGL((shadow_kernel<true>), dim3((nShadow + 63) / 64), dim3(64), 0, stream, sv, pool, nShadow);
+                }
+                if (nExt) {
+                    if (single) hipLaunchKernelGGL((extend_kernel<false>), dim3((nExt + 63) / 64), dim3(64), 0, stream, sv, pool, qOut, nExt);
+                    else hipLaunchKernelGGL((extend_kernel<true>), dim3((nExt + 63) / 64), dim3(64), 0, stream, sv, pool, qOut, nExt);
+                }
+                extension += nExt - h[3];
+                shadow += nShadow;
+                std::swap(qIn, qOut);
+                nActive = nExt;
+            }
+            hipLaunchKernelGGL(resolve_kernel, dim3((batch.nPixels + 255) / 256), dim3(256), 0, stream, pool, st, batch, dRgb);
+            RT_TRY(hipGetLastError());
+        }
+        RT_TRY(hipEventRecord(ev1, stream));
+        RT_TRY(hipStreamSynchronize(stream));
+        if (stats) {
+            float ms = 0;
+            RT_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+            stats->primary_rays = primary;
+            stats->extension_rays = extension;
+            stats->shadow_rays = shadow;
+            stats->device_ms = ms;
+        }
+    }
+    (void)hipEventDestroy(ev0);
+    (void)hipEventDestroy(ev1);
+    return hipSuccess;
+fail:
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
+    return e;
+#undef RT_TRY
 }
 
 } // namespace rt

@@ -1,0 +1,262 @@
+// rt_shade_inl.h -- device functions of the shade / connect stages: samplers, BxDF closures,
+// next-event estimation.  Each function restates the reference arithmetic (float/double mix
+// included); Rand::unit() draws are replaced by the counter-based RNG of rt_rng_inl.h.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_rng_inl.h"
+#include "rt_trace_inl.h"
+
+namespace rt {
+
+#define RT_PI 3.14159265358979323 /* math/Constants.h */
+
+struct RGBf {
+    float r, g, b;
+};
+__device__ __forceinline__ RGBf rgb(float r, float g, float b) { return RGBf{r, g, b}; }
+__device__ __forceinline__ RGBf rgb_mul(RGBf a, RGBf b) { return RGBf{a.r * b.r, a.g * b.g, a.b * b.b}; }
+__device__ __forceinline__ RGBf rgb_scale_f(RGBf a, float s) { return RGBf{a.r * s, a.g * s, a.b * s}; }                                  // RGB::scale(float), film/RGB.h:49-52
+__device__ __forceinline__ RGBf rgb_scale_d(RGBf a, double s) { return RGBf{(float)(a.r * s), (float)(a.g * s), (float)(a.b * s)}; }       // RGB::scale(double), film/RGB.h:44-47
+__device__ __forceinline__ RGBf rgb_div_d(RGBf a, double d) { return rgb_scale_d(a, 1.0 / d); }                                           // film/RGB.h:60-63
+__device__ __forceinline__ RGBf rgb_div_f(RGBf a, float d) { return rgb_scale_f(a, 1.0f / d); }                                           // film/RGB.h:65-68
+
+struct Basis3 {
+    F3 u, v, w;
+};
+// OrthonormalBasis(a), math/OrthonormalBasis.cpp:10-31
+__device__ __forceinline__ Basis3 basis_from(F3 a)
+{
+    Basis3 b;
+    const float length = norm3(a);
+    b.w = a / length;
+    if (fabsf(b.w.x) > fabsf(b.w.y)) {
+        const float inv_length = 1.0f / sqrtf((b.w.x * b.w.x) + (b.w.z * b.w.z));
+        b.u = f3(-b.w.z * inv_length, 0.0f, b.w.x * inv_length);
+    } else {
+        const float inv_length = 1.0f / sqrtf((b.w.y * b.w.y) + (b.w.z * b.w.z));
+        b.u = f3(0.0f, b.w.z * inv_length, -b.w.y * inv_length);
+    }
+    b.v = cross3(b.w, b.u);
+    return b;
+}
+
+// mapSampleToCosineWeightedHemisphere, math/Sampler.h:51-59 (radius 1, exponent 1)
+__device__ __forceinline__ F3 cosine_hemisphere(float r1, float r2)
+{
+    const float cos_theta = sqrtf(r1); // pow(r1, 1/(1+1))
+    const float sin_theta = sqrtf(1.0f - cos_theta * cos_theta);
+    const double phi = 2.0f * RT_PI * r2;
+    const double cos_phi = cos(phi);
+    const double sin_phi = sin(phi);
+    return f3((float)(1.0f * sin_theta * cos_phi), (float)(1.0f * sin_theta * sin_phi), 1.0f * cos_theta);
+}
+
+// sampleP22, material/VNDFGGXSampler.cpp:7-43
+__device__ __forceinline__ void sample_p22(double theta_i, double U1, double U2, float& sx, float& sy)
+{
+    if (theta_i < 0.0001) {
+        const double r = sqrt(U1 / (1 - U1));
+        const double phi = 6.28318530718 * U2;
+        sx = (float)(r * cos(phi));
+        sy = (float)(r * sin(phi));
+        return;
+    }
+    const double tan_theta_i = tan(theta_i);
+    const double a = 1 / (tan_theta_i);
+    const double G1 = 2 / (1 + sqrt(1.0 + 1.0 / (a * a)));
+    const double A = 2.0 * U1 / G1 - 1.0;
+    const double tmp = 1.0 / (A * A - 1.0);
+    const double B = tan_theta_i;
+    const double D = sqrt(B * B * tmp * tmp - (A * A - B * B) * tmp);
+    const double slope_x_1 = B * tmp - D;
+    const double slope_x_2 = B * tmp + D;
+    const double slope_x = (A < 0 || slope_x_2 > 1.0 / tan_theta_i) ? slope_x_1 : slope_x_2;
+    double S;
+    if (U2 > 0.5) { S = 1.0; U2 = 2.0 * (U2 - 0.5); }
+    else          { S = -1.0; U2 = 2.0 * (0.5 - U2); }
+    const double z = (U2 * (U2 * (U2 * 0.27385 - 0.73369) + 0.46341)) / (U2 * (U2 * (U2 * 0.093073 + 0.309420) - 1.000000) + 0.597999);
+    const double slope_y = S * z * sqrt(1.0 + slope_x * slope_x);
+    sx = (float)slope_x;
+    sy = (float)slope_y;
+}
+
+// VNDFGGXSampler::sample, material/VNDFGGXSampler.cpp:53-90
+__device__ __forceinline__ F3 vndf_sample(F3 smoothNormal, F3 worldIncoming, float roughness, double rand1, double rand2)
+{
+    const Basis3 basis = basis_from(smoothNormal);
+    F3 incoming = f3(dot3(basis.u, worldIncoming), dot3(basis.v, worldIncoming), dot3(basis.w, worldIncoming));
+    incoming = normalized3(incoming);
+    const F3 st = normalized3(f3(incoming.x * roughness, incoming.y * roughness, incoming.z));
+    float theta = 0.0f, phi = 0.0f;
+    if (st.z < 0.99999) {
+        theta = acosf(st.z);
+        phi = atan2f(st.y, st.x);
+    }
+    float slx, sly;
+    sample_p22(theta, rand1, rand2, slx, sly);
+    float rx = cosf(phi) * slx - sinf(phi) * sly;
+    float ry = sinf(phi) * slx + cosf(phi) * sly;
+    rx *= roughness;
+    ry *= roughness;
+    const F3 micro = normalized3(f3(-rx, -ry, 1.0f));
+    return f3(basis.u.x * micro.x + (basis.v.x * micro.y + basis.w.x * micro.z),
+              basis.u.y * micro.x + (basis.v.y * micro.y + basis.w.y * micro.z),
+              basis.u.z * micro.x + (basis.v.z * micro.y + basis.w.z * micro.z));
+}
+
+// ggx + brdf, material/GlossyMaterial.cpp:27-66
+__device__ __forceinline__ float ggx_g1(float roughness, F3 v, F3 n, F3 m)
+{
+    const float theta_v = acosf(dot3(v, n));
+    if (dot3(v, m) / dot3(v, n) > 0.0f) {
+        const float tan_theta = tanf(theta_v);
+        return 2.0f / (1.0f + sqrtf(1.0f + (roughness * roughness) * (tan_theta * tan_theta)));
+    }
+    return 0.0f;
+}
+__device__ __forceinline__ float ggx_brdf(float roughness, F3 i, F3 o, F3 n, F3 m)
+{
+    const float g = ggx_g1(roughness, i, n, m) * ggx_g1(roughness, o, n, m);
+    if (g == 0.0f) return 0.0f;
+    if (!(dot3(m, n) > 0)) return 0.0f;
+    const float theta_m = acosf(dot3(m, n));
+    const float aSqr = roughness * roughness;
+    const float tan_theta_m = tanf(theta_m);
+    const float cos_theta_m = cosf(theta_m);
+    const float cos_theta_m_sqr = cos_theta_m * cos_theta_m;
+    const float x = aSqr + tan_theta_m * tan_theta_m;
+    const float d = aSqr / ((float)M_PI * cos_theta_m_sqr * cos_theta_m_sqr * x * x);
+    return g * d / (4.0f * fabsf(dot3(i, n)) * fabsf(dot3(o, n)));
+}
+
+// Triangle::intersect against an area light (renderer/Renderer.cpp:184-204, material/GlossyMaterial.cpp:126-178)
+__device__ __forceinline__ bool area_light_hit(const DevAreaLight& L, F3 o, F3 d, float& t)
+{
+    const F3 a = f3(L.a[0], L.a[1], L.a[2]), b = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
+    const F3 e1 = a - b, e2 = a - c;
+    float4 r0, r1, r2;
+    r0.x = a.x; r0.y = a.y; r0.z = a.z; r0.w = e1.y * e2.z - e1.z * e2.y;
+    r1.x = e1.x; r1.y = e1.y; r1.z = e1.z; r1.w = e1.x * e2.z - e1.z * e2.x;
+    r2.x = e2.x; r2.y = e2.y; r2.z = e2.z; r2.w = e1.x * e2.y - e1.y * e2.x;
+    float be, ga;
+    return tri_test(r0, r1, r2, o, d, t, be, ga);
+}
+
+// light.color * light.intensity / area (the "lightIrradiance" of Renderer.cpp:199-200, GlossyMaterial.cpp:200-201)
+__device__ __forceinline__ RGBf area_light_irradiance(const DevAreaLight& L)
+{
+    const RGBf e = rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity);
+    return rgb_div_d(e, (double)L.area);
+}
+
+struct NeeSample {
+    RGBf radiance;   // value of NextEventEstimation::sample if the shadow ray is unoccluded
+    F3 dir;          // lightDirection
+    float tmax;      // lampT
+    bool valid;      // a light was chosen (otherwise radiance is black and no ray is needed)
+};
+
+// NextEventEstimation::sample with neePointLight / neeAreaLight, material/NextEventEstimation.cpp:8-120,
+// and AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41.  The visibility
+// query itself is left to the shadow stage.
+__device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int sampleCount,
+                                                uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t vertex)
+{
+    NeeSample out;
+    out.radiance = rgb(0, 0, 0);
+    out.dir = f3(0, 0, 0);
+    out.tmax = 0.0f;
+    out.valid = false;
+    const bool hasPoint = sv.nPointLights > 0, hasArea = sv.nAreaLights > 0;
+    const float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f);
+    const float pointP = (hasPoint ? 1.0f : 0.0f) / total;
+    const float areaP = (hasArea ? 1.0f : 0.0f) / total;
+    const float choice = rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_TYPE);
+    if (choice < pointP) {
+        const uint32_t n = sv.nPointLights;
+        const float chosenP = 1.0f / n;
+        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        if (idx > n - 1) idx = n - 1;
+        const DevPointLight& L = sv.pointLights[idx];
+        F3 toLamp = f3(L.pos[0], L.pos[1], L.pos[2]) - hitpoint;
+        const float lampT = norm3(toLamp);
+        toLamp = normalized3(toLamp);
+        const double geometricFactor = 1.0f / (4.0f * RT_PI * (lampT * lampT));
+        const RGBf rad = rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity * geometricFactor);
+        out.radiance = rgb_div_f(rad, pointP * chosenP);
+        out.dir = toLamp;
+        out.tmax = lampT;
+        out.valid = true;
+    } else if (choice < pointP + areaP) {
+        const uint32_t n = sv.nAreaLights;
+        const float chosenP = 1.0f / n;
+        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        if (idx > n - 1) idx = n - 1;
+        const DevAreaLight& L = sv.areaLights[idx];
+        const int nn = (int)sqrt((double)sampleCount);
+        const F3 a = f3(L.a[0], L.a[1], L.a[2]), b = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
+        const F3 v1 = (c - a) / (float)nn;
+        const F3 v2 = (b - a) / (float)nn;
+        const float u = 1.0f - sqrtf(rand_unit(seed, pixel, sample, vertex, DIM_AREA_U));
+        const float v = (1.0f - u) * rand_unit(seed, pixel, sample, vertex, DIM_AREA_V);
+        const int y = sampleI / nn, x = sampleI % nn;
+        const F3 lampPoint = (a + ((u + x) * v1)) + ((v + y) * v2);
+        F3 toLamp = lampPoint - hitpoint;
+        const float lampT = norm3(toLamp);
+        toLamp = normalized3(toLamp);
+        const RGBf lightIrradiance = area_light_irradiance(L);
+        const RGBf lightRadiance = rgb_div_d(lightIrradiance, RT_PI);
+        const F3 nrm = f3(L.normal[0], L.normal[1], L.normal[2]);
+        const float lampAngle = fmaxf(0.0f, dot3(nrm, -toLamp));
+        const float geometricFactor = lampAngle / (lampT * lampT);
+        const RGBf irr = rgb_scale_d(lightRadiance, geometricFactor);
+        out.radiance = rgb_div_f(rgb_scale_d(irr, (double)L.area), areaP * chosenP);
+        out.dir = toLamp;
+        out.tmax = lampT;
+        out.valid = true;
+    }
+    return out;
+}
+
+// IMaterial::hasVariance: Diffuse true (DiffuseMaterial.cpp:228-247 without photon map), Glossy
+// roughness > 0 (GlossyMaterial.cpp:226-229), Emissive false, Mix (MixMaterial.cpp:59-65).
+__device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi)
+{
+    // A mix has variance unless (factor==0 && !first.var) || (factor==1 && !second.var).  Mixes nest
+    // at most 3 deep (checked at scene creation), so the recursion is expanded by hand.
+    struct Eval {
+        const SceneView& sv;
+        __device__ bool leaf(uint32_t m) const
+        {
+            const DevMaterial& M = sv.materials[m];
+            if (M.type == RTGPU_MAT_DIFFUSE) return true;
+            if (M.type == RTGPU_MAT_GLOSSY) return M.roughness > 0.0f;
+            return false;
+        }
+        __device__ bool l3(uint32_t m) const
+        {
+            const DevMaterial& M = sv.materials[m];
+            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
+            const bool noVar = (M.mixFactor == 0.0f && !leaf(M.first)) || (M.mixFactor == 1.0f && !leaf(M.second));
+            return !noVar;
+        }
+        __device__ bool l2(uint32_t m) const
+        {
+            const DevMaterial& M = sv.materials[m];
+            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
+            const bool noVar = (M.mixFactor == 0.0f && !l3(M.first)) || (M.mixFactor == 1.0f && !l3(M.second));
+            return !noVar;
+        }
+        __device__ bool l1(uint32_t m) const
+        {
+            const DevMaterial& M = sv.materials[m];
+            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
+            const bool noVar = (M.mixFactor == 0.0f && !l2(M.first)) || (M.mixFactor == 1.0f && !l2(M.second));
+            return !noVar;
+        }
+    };
+    return Eval{sv}.l1(mi);
+}
+
+} // namespace rt

@@ -22,7 +22,9 @@ __global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const f
     F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
     F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
     uint32_t nb = 0, nt = 0;
-    TraceResult r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
+    TraceResult r;
+    if (INSTANCED && sv.refTop) r = trace_ray_reftop_closest<COUNT>(sv, o, d, stack, lane, nb, nt);
+    else r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
     rtgpu_hit h;
     h.t = r.t;
     h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
@@ -48,8 +50,10 @@ __global__ __launch_bounds__(64) void trace_any_kernel(SceneView sv, const float
     F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
     F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
     uint32_t nb = 0, nt = 0;
-    TraceResult r = trace_ray<INSTANCED, true, false>(sv, o, d, tmax[i], stack, lane, nb, nt);
-    occ[i] = r.inst != kInvalid ? 1 : 0;
+    bool hit;
+    if (INSTANCED && sv.refTop) hit = trace_ray_reftop_any(sv, o, d, tmax[i], stack, lane);
+    else hit = trace_ray<INSTANCED, true, false>(sv, o, d, tmax[i], stack, lane, nb, nt).inst != kInvalid;
+    occ[i] = hit ? 1 : 0;
 }
 
 // PerspectiveCamera::generateRay (camera/PerspectiveCamera.cpp:26-52), aperture 0.

@@ -135,7 +135,8 @@ constexpr int kSentinel = 0x7FFFFFFF;
 // a top-level leaf whose merged box is hit).
 template <bool INSTANCED, bool ANY, bool COUNT>
 __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 wd, float tmax,
-                                                 int (*stack)[64], const int lane, uint32_t& nBoxes, uint32_t& nTris)
+                                                 int (*stack)[64], const int lane, uint32_t& nBoxes, uint32_t& nTris,
+                                                 const uint32_t soloInst = 0)
 {
     TraceResult best;
     best.t = ANY ? tmax : INFINITY;
@@ -156,7 +157,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
         cur = sv.nInst > 1 ? 0 : ~0;
         inMesh = false;
     } else {
-        const DevInstance& in = sv.inst[0];
+        const DevInstance& in = sv.inst[soloInst];
         o = xf_point_inv(in.inv, wo);
         d = xf_vector_inv(in.inv, wd);
         nodeBase = in.root;
@@ -253,7 +254,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
             float t, be, ga;
             if (COUNT) nTris += 1;
             if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
-                const uint32_t ci = INSTANCED ? curInst : 0u;
+                const uint32_t ci = INSTANCED ? curInst : soloInst;
                 if (ANY) {
                     if (t <= tmax) {
                         best.slot = slot; best.inst = ci; best.beta = be; best.gamma = ga;
@@ -276,6 +277,183 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
     }
     if (best.inst == kInvalid) best.t = INFINITY;
     return best;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// Scenes with analytic spheres among several instances: top-level traversal that reproduces the
+// reference's recursion exactly (BVHNode::traceRay, shape/bvh/BVHNode.h:306-397): both child
+// boxes tested at the parent, children visited in the order given by the sign of
+// d[childOrder axis], the second child skipped when the first child's hit is not farther than
+// the second child's entry distance, no pruning by hits found in other subtrees, every instance
+// of a visited leaf tested (InstancedModelList::traceRay, shape/list/InstancedModelList.cpp:99-138).
+// Hit distances are compared in double like the reference's RayHitInfo::t.
+// The frame stack is per-lane private memory (top-level trees are small and shallow); mesh
+// trees below it are walked by trace_ray<false,...> with the LDS stack.
+// ---------------------------------------------------------------------------------------------
+constexpr int kTopFrames = kTopFramesHost;
+
+// AABB::getIntersection (shape/AABB.h:123-131): clamped entry distance, or -1 on a miss.
+__device__ __forceinline__ float box_entry(float lox, float loy, float loz, float hix, float hiy, float hiz, F3 o, F3 inv)
+{
+    float t0;
+    return slab_test(lox, loy, loz, hix, hiy, hiz, o, inv, t0) ? t0 : -1.0f;
+}
+
+template <bool COUNT>
+__device__ __forceinline__ TraceResult trace_ray_reftop_closest(const SceneView& sv, F3 wo, F3 wd, int (*stack)[64], const int lane,
+                                                                uint32_t& nBoxes, uint32_t& nTris)
+{
+    TraceResult best;
+    best.t = INFINITY; best.slot = kInvalid; best.inst = kInvalid; best.beta = 0.0f; best.gamma = 0.0f;
+    double bestT = INFINITY;
+    const F3 winv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+
+    int frameRef[kTopFrames];     // pending second child, or kSentinel for a merge frame
+    float frameTs[kTopFrames];    // entry distance of the pending child
+    double frameT[kTopFrames];    // merge frame: result of the first child
+    int fp = 0;
+    double acc = INFINITY;        // result (t) of the subtree that has just completed
+    int cur = sv.refTopRoot;
+
+    for (;;) {
+        // ---- descend until a subtree completes ------------------------------------------------
+        for (;;) {
+            if (cur >= 0) {
+                const float4* np = sv.nodes + ((size_t)(sv.topRoot + (uint32_t)cur) << 2);
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                if (COUNT) nBoxes += 2;
+                const float tsA = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, wo, winv);
+                const float tsB = box_entry(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, wo, winv);
+                const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+                const uint32_t axis = (uint32_t)__float_as_int(q3.z);
+                const float order = axis == 0 ? wd.x : (axis == 1 ? wd.y : wd.z);
+                int first, second;
+                float tsF, tsS;
+                if (order > 0) { first = ca; tsF = tsA; second = cb; tsS = tsB; }
+                else           { first = cb; tsF = tsB; second = ca; tsS = tsA; }
+                // order == 0: child 1 first as well, but without the early exit (flag in frameT)
+                if (tsF >= 0) {
+                    if (fp >= kTopFrames) return best; // cannot happen: depth is checked at scene creation
+                    frameRef[fp] = second;
+                    frameTs[fp] = tsS;
+                    frameT[fp] = (order == 0) ? 1.0 : 0.0; // 1 = no early exit
+                    ++fp;
+                    acc = INFINITY;
+                    cur = first;
+                } else if (tsS >= 0) {
+                    acc = INFINITY;
+                    cur = second;
+                } else {
+                    acc = INFINITY;
+                    break;
+                }
+            } else {
+                // leaf: InstancedModelList::traceRay over [first, first+count)
+                const uint32_t leaf = (uint32_t)(~cur);
+                const uint32_t first = leaf >> 8, count = (leaf & 255u) + 1u;
+                double leafT = INFINITY;
+                TraceResult leafBest = best;
+                bool leafHit = false;
+                for (uint32_t k = 0; k < count; ++k) {
+                    const uint32_t ii = sv.instOrder[first + k];
+                    const DevInstance& in = sv.inst[ii];
+                    if (in.shape < 0) {
+                        const F3 o = xf_point_inv(in.inv, wo), d = xf_vector_inv(in.inv, wd);
+                        double ts;
+                        if (COUNT) nTris += 1;
+                        if (sphere_test(o, d, ts) && (!leafHit || leafT > ts)) {
+                            leafHit = true; leafT = ts;
+                            leafBest.t = (float)ts; leafBest.slot = kInvalid; leafBest.inst = ii; leafBest.beta = 0.0f; leafBest.gamma = 0.0f;
+                        }
+                    } else {
+                        const TraceResult r = trace_ray<false, false, COUNT>(sv, wo, wd, INFINITY, stack, lane, nBoxes, nTris, ii);
+                        if (r.inst != kInvalid && (!leafHit || leafT > (double)r.t)) {
+                            leafHit = true; leafT = (double)r.t;
+                            leafBest = r;
+                        }
+                    }
+                }
+                acc = leafHit ? leafT : INFINITY;
+                if (leafHit && (best.inst == kInvalid || bestT > leafT)) { bestT = leafT; best = leafBest; }
+                break;
+            }
+        }
+        // ---- unwind -------------------------------------------------------------------------------
+        bool descend = false;
+        while (fp > 0) {
+            --fp;
+            const int ref = frameRef[fp];
+            if (ref == kSentinel) {
+                // merge: result(N) = first child's hit unless the second child's is strictly closer
+                const double tf = frameT[fp];
+                if (!(tf > acc)) acc = tf;
+                continue;
+            }
+            const float ts = frameTs[fp];
+            const bool noEarlyExit = frameT[fp] != 0.0;
+            const bool hitFirst = acc < INFINITY;
+            if (ts >= 0 && (!hitFirst || noEarlyExit || acc > (double)ts)) {
+                if (hitFirst) { frameRef[fp] = kSentinel; frameT[fp] = acc; ++fp; }
+                acc = INFINITY;
+                cur = ref;
+                descend = true;
+                break;
+            }
+            // second child not visited: N completes with the first child's result
+        }
+        if (!descend) break;
+    }
+    if (best.inst == kInvalid) best.t = INFINITY;
+    return best;
+}
+
+// BVHNode::testVisibility (shape/bvh/BVHNode.h:399-446) + InstancedModelList::testVisibility
+// (shape/list/InstancedModelList.cpp:205-233) on the reference-shaped top-level tree: a child is
+// entered when its box is hit with entry <= maxT; the answer (anything hit within maxT) does not
+// depend on the visiting order.
+__device__ __forceinline__ bool trace_ray_reftop_any(const SceneView& sv, F3 wo, F3 wd, float tmax, int (*stack)[64], const int lane)
+{
+    const F3 winv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+    int pending[kTopFrames];
+    int pp = 0;
+    int cur = sv.refTopRoot;
+    uint32_t nb = 0, nt = 0;
+    for (;;) {
+        if (cur >= 0) {
+            const float4* np = sv.nodes + ((size_t)(sv.topRoot + (uint32_t)cur) << 2);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            float t0a, t0b;
+            const bool ha = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, wo, winv, t0a) && t0a <= tmax;
+            const bool hb = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, wo, winv, t0b) && t0b <= tmax;
+            const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+            if (ha && hb) {
+                if (pp >= kTopFrames) return false;
+                pending[pp++] = cb;
+                cur = ca;
+                continue;
+            }
+            if (ha) { cur = ca; continue; }
+            if (hb) { cur = cb; continue; }
+        } else {
+            const uint32_t leaf = (uint32_t)(~cur);
+            const uint32_t first = leaf >> 8, count = (leaf & 255u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t ii = sv.instOrder[first + k];
+                const DevInstance& in = sv.inst[ii];
+                if (in.shape < 0) {
+                    const F3 o = xf_point_inv(in.inv, wo), d = xf_vector_inv(in.inv, wd);
+                    double ts;
+                    if (sphere_test(o, d, ts) && ts <= (double)tmax) return true;
+                } else {
+                    const TraceResult r = trace_ray<false, true, false>(sv, wo, wd, tmax, stack, lane, nb, nt, ii);
+                    if (r.inst != kInvalid) return true;
+                }
+            }
+        }
+        if (pp == 0) return false;
+        cur = pending[--pp];
+    }
 }
 
 } // namespace rt

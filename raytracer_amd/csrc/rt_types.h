@@ -43,6 +43,10 @@ struct TriRec {
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 4) | (count - 1)); }
+// top-level leaves (instances): up to 256 instances per leaf, first < 2^23
+constexpr uint32_t kMaxTopLeaf = 256;
+constexpr int kTopFramesHost = 48;   // per-lane frame stack of the reference-order top-level walk
+inline int32_t encode_top_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 8) | (count - 1)); }
 
 struct DevInstance {
     double inv[12];      // rows 0..2 of the world->object 4x4 (row 3 must be 0 0 0 1)

@@ -280,9 +280,9 @@ def interior_scene(detail=1.0, seed=1):
             x = 2.0 + c * (L - 4.0) / (ncol - 1)
             mat = 1 if (c + row) % 3 == 0 else 0
             parts.append((*cylinder((x, 0.0, z), 0.42, H * 0.72, seg, stk, flute=0.06), mat))
-            v, f = grid_quad((x - 0.7, H * 0.72, z - 0.7), (0, 0, 1.4), (1.4, 0, 0), 4, 4)  # capital slab (top)
+            v, f = grid_quad((x - 0.7, H * 0.72 + 0.3, z - 0.7), (0, 0, 1.4), (1.4, 0, 0), 4, 4)  # capital slab (top face)
             parts.append((v, f, 0))
-            v, f = grid_quad((x - 0.7, H * 0.72, z - 0.7), (1.4, 0, 0), (0, 0, 1.4), 4, 4)  # capital slab (bottom)
+            v, f = grid_quad((x - 0.7, H * 0.72 + 0.01, z - 0.7), (1.4, 0, 0), (0, 0, 1.4), 4, 4)  # capital slab (bottom face)
             parts.append((v, f, 0))
     us = uv_sphere(max(8, int(48 * math.sqrt(detail))), max(4, int(24 * math.sqrt(detail))))
     for k in range(6):

@@ -1,0 +1,67 @@
+"""Generates the golden fixtures under tests/golden/ with the CPU oracle.
+
+The reference cannot be built in this container (Eigen3 / legacy TBB absent), so these vectors
+come from the oracle (oracle/rt_oracle.cpp), whose parity with the reference is pinned only by
+the reference's own known-answer tests (see tests/test_oracle_known_answers.py).  They guard the
+oracle and the HIP path against regressions.
+
+    python tests/golden/make_golden.py
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+
+import oracle  # noqa: E402
+from raytracer_amd import abi, scenes  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def main():
+    # G-1: config 1 (101 mesh instances + 16 analytic spheres), 640x480 pixel-centre primary rays and
+    # the shadow ray from each hit towards the point light
+    sc, cam_m, yfov = scenes.c1_scene(seed=0)
+    S = oracle.OracleScene(sc)
+    cam = oracle.camera_from_transform(scenes.x_fov_degrees(yfov, 640 / 480), cam_m)
+    st = abi.make_settings(640, 480, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    o, d = oracle.generate_primary(cam, st)
+    hits = S.trace_closest(o, d)
+    light = np.asarray(sc.point_lights[0][0], dtype=np.float32)
+    hp = (o + d * hits["t"][:, None]).astype(np.float32)
+    hit_mask = hits["inst"] != abi.INVALID_ID
+    hp[~hit_mask] = 0
+    to_l = light[None, :] - hp
+    lamp_t = np.linalg.norm(to_l, axis=1).astype(np.float32)
+    ldir = (to_l / np.maximum(lamp_t, 1e-20)[:, None]).astype(np.float32)
+    so = (hp + ldir * np.float32(0.0001)).astype(np.float32)
+    occ = S.trace_any(so, ldir, lamp_t)
+    occ[~hit_mask] = 0
+    sel = np.arange(0, len(o), 8)
+    np.savez_compressed(os.path.join(HERE, "c1_primary_stride8.npz"),
+                        index=sel.astype(np.uint32), t=hits["t"][sel], prim=hits["prim"][sel], inst=hits["inst"][sel],
+                        occluded=occ[sel],
+                        sha_t=sha(hits["t"]), sha_prim=sha(hits["prim"]), sha_inst=sha(hits["inst"]), sha_occ=sha(occ))
+    # G-2: incoherent rays against config 1
+    ro, rd = scenes.random_rays(20000, (-1.5, -1.5, -1.5), (2.5, 2.5, 1.5), seed=3)
+    rh = S.trace_closest(ro, rd)
+    np.savez_compressed(os.path.join(HERE, "c1_random_rays.npz"), t=rh["t"], prim=rh["prim"], inst=rh["inst"])
+    # G-4: integrator image of the closed diffuse+glossy box (one point light, one area light)
+    bs, bcam_m, byfov = scenes.box_scene()
+    BS = oracle.OracleScene(bs)
+    bcam = oracle.camera_from_transform(scenes.x_fov_degrees(byfov, 48 / 36), bcam_m)
+    bst = abi.make_settings(48, 36, geometry_aa=4, material_aa=4, seed=11)
+    img, stats = BS.render(bcam, bst, threads=1)
+    np.savez_compressed(os.path.join(HERE, "box_render_48x36_g4_m4_seed11.npz"), image=img,
+                        rays=np.array([stats.primary_rays, stats.extension_rays, stats.shadow_rays], dtype=np.uint64))
+    print("fixtures written to", HERE)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,311 @@
+"""GPU parity tests: every call goes through the C ABI of librtgpu.so and is compared with the CPU
+oracle on the same seeded inputs and with the committed golden fixtures.
+
+Bars: primitive / instance ids bit-exact except where two primitives are hit at bit-identical
+distance (the reference's own pick then depends on its unstable-sort tree order; the kernel picks
+the smaller id); hit distances bit-exact for triangles (<= 1e-5 relative is the contract);
+images at matched random streams within 1e-4 relative RMSE.
+"""
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import abi, api, scenes
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def assert_hits_match(S, got, o, d, ref=None, allow_ties=True):
+    ref = S.trace_closest(o, d) if ref is None else ref
+    same = (ref["inst"] == got["inst"]) & (ref["prim"] == got["prim"])
+    bad = np.nonzero(~same)[0]
+    if len(bad):
+        assert allow_ties, f"{len(bad)} id mismatches"
+        brute, tied = S.brute_closest(o[bad], d[bad])
+        assert np.all(tied > 1), f"{int((tied <= 1).sum())} id mismatches that are not exact-distance ties"
+        assert np.array_equal(brute["prim"], got["prim"][bad]) and np.array_equal(brute["inst"], got["inst"][bad])
+    hit = ref["inst"] != abi.INVALID_ID
+    assert np.array_equal(hit, got["inst"] != abi.INVALID_ID)
+    rel = np.abs(ref["t"][hit] - got["t"][hit]) / np.maximum(np.abs(ref["t"][hit]), 1e-30)
+    assert rel.size == 0 or rel.max() <= 1e-5
+    tri = hit & same & (ref["prim"] != abi.INVALID_ID)
+    assert np.array_equal(ref["t"][tri], got["t"][tri])
+    assert np.array_equal(ref["beta"][tri], got["beta"][tri]) and np.array_equal(ref["gamma"][tri], got["gamma"][tri])
+    return len(bad)
+
+
+def c1_primary(W=640, H=480, **kw):
+    sc, cam_m, yfov = scenes.c1_scene(seed=0, **kw)
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    o, d = oracle.generate_primary(cam, st)
+    return sc, cam, st, o, d
+
+
+def test_two_spheres_known_answer():
+    """raytracer/test/BVH.cpp:18-49 through the GPU path."""
+    with api.Scene(scenes.two_spheres_scene()) as g:
+        h = g.trace_rays(np.zeros((2, 3), np.float32), np.array([[-1, 0, 0], [1, 0, 0]], np.float32))
+        assert list(h["inst"]) == [0, 1] and list(h["prim"]) == [abi.INVALID_ID] * 2 and list(h["t"]) == [1.0, 1.0]
+        assert g.trace_ray((0, 0, 0), (0, 1, 0)) is None
+        assert g.trace_ray((-2, 0, 0), (1, 0, 0)) is not None and g.trace_ray((-2, 0, 0), (1, 0, 0))["inst"] == 1  # inside sphere 0: missed
+
+
+def test_c1_instanced_primary_and_shadow_match_oracle_and_golden():
+    sc, cam, st, o, d = c1_primary()
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        got = g.trace_rays(o, d)
+        n_ties = assert_hits_match(S, got, o, d)
+        assert n_ties == 0
+        gold = np.load(os.path.join(GOLDEN, "c1_primary_stride8.npz"))
+        sel = gold["index"]
+        assert np.array_equal(got["t"][sel], gold["t"]) and np.array_equal(got["prim"][sel], gold["prim"]) and np.array_equal(got["inst"][sel], gold["inst"])
+        # shadow rays towards the point light: o = p + l * 1e-4, tmax = |L - p| (material/NextEventEstimation.cpp:10-16)
+        hit = got["inst"] != abi.INVALID_ID
+        light = np.asarray(sc.point_lights[0][0], dtype=np.float32)
+        hp = (o + d * got["t"][:, None]).astype(np.float32)
+        hp[~hit] = 0
+        to_l = light[None, :] - hp
+        lamp_t = np.linalg.norm(to_l, axis=1).astype(np.float32)
+        ldir = (to_l / np.maximum(lamp_t, 1e-20)[:, None]).astype(np.float32)
+        so = (hp + ldir * np.float32(0.0001)).astype(np.float32)
+        occ = g.test_visibility(so, ldir, lamp_t)
+        ref_occ = S.trace_any(so, ldir, lamp_t)
+        assert np.array_equal(occ[hit], ref_occ[hit])
+        assert np.array_equal(occ[sel][hit[sel]], gold["occluded"][hit[sel]])
+
+
+def test_c1_soup_matches_instanced_geometry():
+    sc, cam, st, o, d = c1_primary(soup=True, with_spheres=False)
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        got = g.trace_rays(o, d)
+        assert_hits_match(S, got, o, d)
+        assert int((got["inst"] != abi.INVALID_ID).sum()) > 100000
+
+
+@pytest.mark.parametrize("instanced_spheres", [True, False])
+def test_incoherent_rays_c1(instanced_spheres):
+    sc, _, _ = scenes.c1_scene(seed=0, with_spheres=instanced_spheres)
+    S = oracle.OracleScene(sc)
+    o, d = scenes.random_rays(20000, (-1.5, -1.5, -1.5), (2.5, 2.5, 1.5), seed=3)
+    with api.Scene(sc) as g:
+        got = g.trace_rays(o, d)
+        assert_hits_match(S, got, o, d)
+        if instanced_spheres:
+            gold = np.load(os.path.join(GOLDEN, "c1_random_rays.npz"))
+            assert np.array_equal(got["t"], gold["t"]) and np.array_equal(got["prim"], gold["prim"]) and np.array_equal(got["inst"], gold["inst"])
+        for scale in (0.5, 0.999, 1.001, 4.0):
+            tmax = np.where(np.isfinite(got["t"]), got["t"] * scale, 3.0).astype(np.float32)
+            assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
+
+
+def test_interior_incoherent_rays_and_edge_rays():
+    """Axis-aligned tessellated walls: rays aimed exactly at shared edges/vertices produce the
+    exact-distance ties that are the documented id exception."""
+    sc, _, _ = scenes.interior_scene(detail=0.08)
+    S = oracle.OracleScene(sc)
+    o, d = scenes.random_rays(60000, (0.5, 0.5, 0.5), (23, 8, 9), seed=4)
+    v = sc.meshes[0].vertices
+    rng = np.random.RandomState(0)
+    targets = v[rng.randint(0, len(v), 5000)]
+    eo = np.tile(np.array([[12.0, 4.0, 5.0]], np.float32), (5000, 1))
+    ed = (targets - eo).astype(np.float32)
+    ed /= np.linalg.norm(ed, axis=1, keepdims=True)
+    o = np.concatenate([o, eo]).astype(np.float32)
+    d = np.concatenate([d, ed]).astype(np.float32)
+    with api.Scene(sc) as g:
+        got = g.trace_rays(o, d)
+        n_ties = assert_hits_match(S, got, o, d)
+        assert n_ties > 0  # the tie path of the test is exercised
+        tmax = (got["t"] * 0.9999).astype(np.float32)
+        assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
+
+
+def test_empty_and_ragged_batches():
+    sc, _, _ = scenes.c1_scene(n_small=5)
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        assert g.trace_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).shape == (0,)
+        assert g.test_visibility(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32), np.zeros(0, np.float32)).shape == (0,)
+        for n in (1, 63, 64, 65, 1000):
+            o, d = scenes.random_rays(n, (-1, -1, -3), (2, 2, -2), seed=n)
+            d = np.tile(np.array([[0.05, 0.02, 1.0]], np.float32), (n, 1))
+            d /= np.linalg.norm(d, axis=1, keepdims=True)
+            assert_hits_match(S, g.trace_rays(o, d), o, d)
+        with pytest.raises(ValueError):
+            g.trace_rays(np.zeros((3, 3), np.float32), np.zeros((2, 3), np.float32))
+
+
+def test_degenerate_rays_axis_aligned_and_zero_components():
+    """Directions with exact zeros (1/d = inf in the slab test) and rays starting on geometry."""
+    sc, _, _ = scenes.box_scene()
+    S = oracle.OracleScene(sc)
+    o = np.array([[2, 2, 2]] * 6 + [[2, 0, 2], [1.3, 1.1, 0.7]], np.float32)
+    d = np.array([[1, 0, 0], [-1, 0, 0], [0, 1, 0], [0, -1, 0], [0, 0, 1], [0, 0, -1], [0, 1, 0], [0.6, 0, 0.8]], np.float32)
+    with api.Scene(sc) as g:
+        assert_hits_match(S, g.trace_rays(o, d), o, d)
+
+
+def test_primary_ray_generation_matches_oracle():
+    import torch
+    sc, cam_m, yfov = scenes.c1_scene(n_small=3)
+    for jitter, G in ((abi.JITTER_CENTER, 1), (abi.JITTER_RANDOM, 1), (abi.JITTER_RANDOM, 16)):
+        cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, 96 / 64), cam_m)
+        st = abi.make_settings(96, 64, geometry_aa=G, material_aa=3, seed=5, jitter_mode=jitter, tile=(8, 4, 90, 60))
+        n = (st.x_end - st.x_start) * (st.y_end - st.y_start)
+        for si in range(min(G, 3)):
+            d_o = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+            d_d = torch.empty((n, 3), dtype=torch.float32, device="cuda")
+            api.generate_primary_device(cam, st, si, d_o, d_d, torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            ro, rd = oracle.generate_primary(cam, st, si)
+            assert np.array_equal(d_o.cpu().numpy(), ro)
+            assert np.abs(d_d.cpu().numpy() - rd).max() <= 1.2e-7  # sqrt/divide are correctly rounded on both sides
+
+
+def rel_rmse(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)) / max(float(np.mean(b)), 1e-12))
+
+
+@pytest.mark.parametrize("name,G,M,W,H", [("box", 4, 4, 48, 36), ("box", 16, 16, 32, 24), ("mirror", 4, 16, 40, 30), ("c1", 4, 8, 80, 60)])
+def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
+    """The oracle and the GPU integrator draw the same counter-based random numbers, so images agree to
+    float rounding (forward throughput vs. the reference's backward evaluation; device vs. host
+    libm): relative RMSE <= 1e-4 and PSNR >= 80 dB; a decision that flips on a rounding difference
+    may change single pixels, bounded by the RMSE."""
+    if name == "c1":
+        sc, cam_m, yfov = scenes.c1_scene(n_small=20)
+    else:
+        sc, cam_m, yfov = scenes.box_scene(with_mirror=(name == "mirror"))
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, seed=11)
+    ref, rstats = oracle.OracleScene(sc).render(cam, st)
+    with api.Scene(sc) as g:
+        img, stats = api.Renderer().render(g, cam, st)
+    assert np.isfinite(img).all() and img.min() >= 0
+    assert rel_rmse(img, ref) <= 1e-4
+    mse = float(np.mean((img - ref) ** 2))
+    assert 10 * np.log10(float(ref.max()) ** 2 / max(mse, 1e-30)) >= 80.0
+    assert stats.primary_rays == rstats.primary_rays == W * H * G
+    # the wavefront skips queries whose result cannot contribute (last path vertex), never adds any
+    assert stats.shadow_rays <= rstats.shadow_rays and stats.shadow_rays >= 0.97 * rstats.shadow_rays
+    assert stats.extension_rays <= rstats.extension_rays * 1.0001 and stats.extension_rays >= 0.97 * rstats.extension_rays
+    if (name, G, M) == ("box", 4, 4):
+        gold = np.load(os.path.join(GOLDEN, "box_render_48x36_g4_m4_seed11.npz"))
+        assert rel_rmse(img, gold["image"]) <= 1e-4
+
+
+def test_render_statistically_matches_other_seeds():
+    """Estimator check independent of the shared RNG: GPU image with seed A vs the oracle's mean over
+    other seeds; tolerance from the oracle's own seed-to-seed spread (k = 4 sigma of the mean)."""
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 24, 18
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    S = oracle.OracleScene(sc)
+    refs = np.stack([S.render(cam, abi.make_settings(W, H, geometry_aa=16, material_aa=16, seed=100 + k))[0] for k in range(6)])
+    mean, sd = refs.mean(axis=0), refs.std(axis=0, ddof=1)
+    with api.Scene(sc) as g:
+        img, _ = api.Renderer().render(g, cam, abi.make_settings(W, H, geometry_aa=16, material_aa=16, seed=7))
+    # image-level brightness and per-pixel deviation
+    assert abs(img.mean() - mean.mean()) <= 4 * refs.mean(axis=(1, 2, 3)).std(ddof=1) + 1e-3
+    z = np.abs(img - mean) / (sd * np.sqrt(1 + 1 / 6) + 1e-3)
+    assert np.mean(z < 4) > 0.97
+
+
+def test_render_tile_and_batching_do_not_change_pixels():
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 40, 30
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    with api.Scene(sc) as g:
+        full, _ = api.Renderer().render(g, cam, abi.make_settings(W, H, geometry_aa=4, material_aa=4, seed=2))
+        fb = np.full((H, W, 3), -1.0, dtype=np.float32)
+        part, _ = api.Renderer().render(g, cam, abi.make_settings(W, H, geometry_aa=4, material_aa=4, seed=2, tile=(10, 5, 30, 25)), framebuffer=fb)
+        assert np.array_equal(part[5:25, 10:30], full[5:25, 10:30])
+        mask = np.ones((H, W), bool)
+        mask[5:25, 10:30] = False
+        assert np.all(part[mask] == -1.0)  # only the tile is written
+        os.environ["RTGPU_BATCH_PATHS"] = "4096"
+        try:
+            small, _ = api.Renderer().render(g, cam, abi.make_settings(W, H, geometry_aa=4, material_aa=4, seed=2))
+        finally:
+            del os.environ["RTGPU_BATCH_PATHS"]
+        assert np.array_equal(small, full)
+        again, _ = api.Renderer().render(g, cam, abi.make_settings(W, H, geometry_aa=4, material_aa=4, seed=2))
+        assert np.array_equal(again, full)  # run-to-run deterministic
+
+
+def test_sharded_frame_is_bit_identical_to_single_pass():
+    """The multi-GPU decomposition (interleaved row bands) on one GPU: assembling the bands of
+    world = 1, 2, 4 gives the same frame bit for bit."""
+    import torch
+    from raytracer_amd import distributed
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 32, 26
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=9)
+    dev = torch.device("cuda", 0)
+    with api.Scene(sc) as g:
+        full, _ = api.Renderer().render(g, cam, st)
+        for world in (1, 2, 4):
+            frame = np.zeros_like(full)
+            for rank in range(world):
+                fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+                for y0, y1 in distributed.rank_bands(H, world, rank):
+                    bst = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=9, tile=(0, y0, W, y1))
+                    api.Renderer().render_device(g, cam, bst, fb)
+                    frame[y0:y1] = fb[y0:y1].cpu().numpy()
+            assert np.array_equal(frame, full)
+
+
+def test_materials_emissive_mix_and_environment():
+    sc, cam_m, yfov = scenes.box_scene()
+    sc.materials.append(abi.MaterialData(abi.MAT_CONSTMIX, mix_factor=0.4, first=0, second=1))  # id 6
+    sc.materials.append(abi.MaterialData(abi.MAT_CONSTMIX, mix_factor=1.0, first=0, second=5))  # id 7: always emissive
+    tm = sc.meshes[0].tri_material.copy()
+    tm[tm == 2] = 6
+    tm[tm == 3] = 7
+    sc.meshes[0].tri_material = tm
+    sc.env = ((0.2, 0.3, 0.5), 1.5)
+    # open the box: drop the ceiling so that paths can escape to the environment
+    keep = np.ones(len(tm), bool)
+    keep[72:144] = False
+    sc.meshes[0].indices = sc.meshes[0].indices[keep]
+    sc.meshes[0].tri_material = tm[keep]
+    W, H = 40, 30
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=4, material_aa=8, seed=21)
+    ref, _ = oracle.OracleScene(sc).render(cam, st)
+    with api.Scene(sc) as g:
+        img, _ = api.Renderer().render(g, cam, st)
+    assert rel_rmse(img, ref) <= 1e-4
+
+
+def test_scaled_rotated_instances_and_scene_errors():
+    m = scenes.uv_sphere(16, 8)
+    sc = abi.SceneData()
+    sc.meshes = [m]
+    sc.materials = [abi.MaterialData(abi.MAT_DIFFUSE, (0.5, 0.5, 0.5))]
+    rng = np.random.RandomState(2)
+    for k in range(40):
+        q = rng.normal(size=4)
+        q /= np.linalg.norm(q)
+        tr, inv = scenes.trs(rng.uniform(-3, 3, 3), q, rng.uniform(0.2, 1.2, 3))
+        sc.instances.append(abi.InstanceData(0 if k % 4 else abi.SHAPE_SPHERE, 0, tr, inv))
+    S = oracle.OracleScene(sc)
+    o, d = scenes.random_rays(30000, (-5, -5, -5), (5, 5, 5), seed=8)
+    with api.Scene(sc) as g:
+        assert_hits_match(S, g.trace_rays(o, d), o, d)
+        tmax = np.full(len(o), 2.5, np.float32)
+        assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
+    bad = abi.SceneData(meshes=[m], materials=sc.materials, instances=[abi.InstanceData(3, 0, np.eye(4))])
+    with pytest.raises(ValueError):
+        api.Scene(bad)
+    proj = np.eye(4)
+    proj[3, 2] = 0.1
+    with pytest.raises(ValueError):
+        api.Scene(abi.SceneData(meshes=[m], materials=sc.materials, instances=[abi.InstanceData(0, 0, proj, np.eye(4))]))

@@ -1,0 +1,170 @@
+"""CPU tests: the oracle against the reference's own known-answer tests and its golden fixtures.
+
+These are the only vectors the reference holds for the hot path (raytracer/test/*.cpp); everything
+else about the oracle's parity with the reference is unpinned (restated from the source text).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import abi, scenes
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def f3(*v):
+    return (C.c_float * 3)(*v)
+
+
+def float_eq(a, b, ulps=4):
+    """gtest's ASSERT_FLOAT_EQ: within 4 ULPs."""
+    a32, b32 = np.float32(a), np.float32(b)
+    ia, ib = int(a32.view(np.int32)), int(b32.view(np.int32))
+    if ia < 0:
+        ia = -(ia & 0x7FFFFFFF)
+    if ib < 0:
+        ib = -(ib & 0x7FFFFFFF)
+    return abs(ia - ib) <= ulps
+
+
+def test_triangle_surface_area():
+    """raytracer/test/Triangle.cpp:7-23"""
+    L = oracle.lib()
+    assert float_eq(L.orc_triangle_area(f3(1, 1, 1), f3(3, 1, 1), f3(1, 2, 1)), 1)
+    assert float_eq(L.orc_triangle_area(f3(0, 1, 0), f3(-1, 1, 1), f3(2, 1, 2)), 2)
+
+
+def test_aabb_transformed_merge_area():
+    """raytracer/test/Box.cpp:26-54"""
+    L = oracle.lib()
+    lo, hi = f3(0, 0, 0), f3(0, 0, 0)
+    m = (C.c_double * 16)(*scenes.translate(10, 10, 10).reshape(-1).tolist())
+    L.orc_aabb_of_transformed(f3(-1, -2, -1), f3(1, 2, 1), m, lo, hi)
+    assert list(lo) == [9, 8, 9] and list(hi) == [11, 12, 11]
+    assert L.orc_aabb_area(f3(0, 1, 2), f3(3, 3, 3)) == 22
+    L.orc_aabb_merge(f3(-2, -1, -1), f3(2, 1, 1), f3(-1, 2, -3), f3(1, 3, 3), lo, hi)
+    assert list(lo) == [-2, -1, -3] and list(hi) == [2, 3, 3]
+
+
+@pytest.mark.parametrize("quat,vec,expect", [
+    ((0.7071068, 0, 0, 0.7071068), (1, 0, 0), (1, 0, 0)),
+    ((0.7071068, 0, 0, 0.7071068), (0, 1, 0), (0, 0, 1)),
+    ((0.7071068, 0, 0, 0.7071068), (0, 0, 1), (0, -1, 0)),
+    ((0, 0.7071068, 0, 0.7071068), (1, 0, 0), (0, 0, -1)),
+    ((0, 0.7071068, 0, 0.7071068), (0, 0, 1), (1, 0, 0)),
+    ((0, 0, 0.7071068, 0.7071068), (1, 0, 0), (0, 1, 0)),
+    ((0, 0, 0.7071068, 0.7071068), (0, 1, 0), (-1, 0, 0)),
+    ((0.3535533, -0.3535533, 0.1464466, 0.8535534), (1, 0, 0), (0.707106888, 0.00000011481512, 0.707106888)),
+])
+def test_quaternion_rotation(quat, vec, expect):
+    """raytracer/test/Quaternion.cpp:7-69 (ASSERT_FLOAT_EQ; exact zeros are compared with an absolute bound
+    because gtest's ULP distance to 0 is only meaningful for denormals: the reference's own results
+    for those components are ~1e-8, which its ASSERT_FLOAT_EQ(x, 0) calls reject too)."""
+    L = oracle.lib()
+    m, inv = (C.c_double * 16)(), (C.c_double * 16)()
+    L.orc_rotate_quaternion(*quat, m, inv)
+    out = f3(0, 0, 0)
+    L.orc_transform_vector(m, f3(*vec), out)
+    for got, want in zip(out, expect):
+        if want == 0:
+            assert abs(got) < 1e-6
+        else:
+            assert float_eq(got, want), (got, want)
+
+
+def test_bvh_two_spheres():
+    """raytracer/test/BVH.cpp:18-49: unit spheres at x = -2 / +2, rays from the origin along -x / +x
+    hit sphere 1 / sphere 2 (t = 1)."""
+    S = oracle.OracleScene(scenes.two_spheres_scene())
+    o = np.zeros((2, 3), np.float32)
+    d = np.array([[-2, 0, 0], [2, 0, 0]], np.float32)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    h = S.trace_closest(o, d)
+    assert list(h["inst"]) == [0, 1]
+    assert list(h["prim"]) == [abi.INVALID_ID] * 2
+    assert np.allclose(h["t"], 1.0)
+
+
+def test_sphere_inside_misses():
+    """shape/Sphere.cpp:37-38: largestT = min(t1, t0), so a ray that starts inside the sphere misses."""
+    L = oracle.lib()
+    t = C.c_double()
+    assert L.orc_sphere_intersect(f3(0, 0, 0), f3(1, 0, 0), C.byref(t)) == 0
+    assert L.orc_sphere_intersect(f3(-3, 0, 0), f3(1, 0, 0), C.byref(t)) == 1 and t.value == 2.0
+
+
+def test_triangle_intersect_basics():
+    """math/Triangle.h:34-101: no back-face culling, t < 0 rejected, edges inclusive."""
+    L = oracle.lib()
+    be, ga, t = C.c_float(), C.c_float(), C.c_float()
+    a, b, c = f3(0, 0, 0), f3(1, 0, 0), f3(0, 1, 0)
+    assert L.orc_triangle_intersect(f3(0.25, 0.25, 1), f3(0, 0, -1), a, b, c, be, ga, t) == 1
+    assert (be.value, ga.value, t.value) == (0.25, 0.25, 1.0)
+    assert L.orc_triangle_intersect(f3(0.25, 0.25, -1), f3(0, 0, 1), a, b, c, be, ga, t) == 1  # from behind
+    assert L.orc_triangle_intersect(f3(0.25, 0.25, 1), f3(0, 0, 1), a, b, c, be, ga, t) == 0   # t < 0
+    assert L.orc_triangle_intersect(f3(0.5, 0.5, 1), f3(0, 0, -1), a, b, c, be, ga, t) == 1    # on the edge beta+gamma == 1
+    assert L.orc_triangle_intersect(f3(0.75, 0.5, 1), f3(0, 0, -1), a, b, c, be, ga, t) == 0
+    assert L.orc_triangle_intersect(f3(0.25, 0.25, 1), f3(1, 0, 0), a, b, c, be, ga, t) == 0   # parallel: pDet == 0
+
+
+def test_rng_is_uniform_and_keyed():
+    L = oracle.lib()
+    v = np.array([L.orc_rand_unit(1, p, 0, 0, 1) for p in range(4000)])
+    assert 0.0 <= v.min() and v.max() < 1.0 and abs(v.mean() - 0.5) < 0.02
+    assert L.orc_rand_unit(1, 5, 0, 0, 1) == L.orc_rand_unit(1, 5, 0, 0, 1)
+    assert L.orc_rand_unit(1, 5, 0, 0, 1) != L.orc_rand_unit(2, 5, 0, 0, 1)
+
+
+def test_tree_closest_equals_exhaustive_search():
+    """The reference-order tree walk must find the globally closest primitive (boxes are conservative
+    for meshes); only bit-equal distances may resolve to a different primitive."""
+    sc, _, _ = scenes.c1_scene(n_small=12, with_spheres=False)
+    S = oracle.OracleScene(sc)
+    o, d = scenes.random_rays(3000, (-1.5, -1.5, -1.5), (2.5, 2.5, 1.5), seed=5)
+    tree = S.trace_closest(o, d)
+    brute, tied = S.brute_closest(o, d)
+    assert np.array_equal(tree["t"], brute["t"])
+    diff = (tree["prim"] != brute["prim"]) | (tree["inst"] != brute["inst"])
+    assert np.all(tied[diff] > 1)
+
+
+def test_golden_c1_primary():
+    g = np.load(os.path.join(GOLDEN, "c1_primary_stride8.npz"))
+    sc, cam_m, yfov = scenes.c1_scene(seed=0)
+    S = oracle.OracleScene(sc)
+    cam = oracle.camera_from_transform(scenes.x_fov_degrees(yfov, 640 / 480), cam_m)
+    st = abi.make_settings(640, 480, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    o, d = oracle.generate_primary(cam, st)
+    sel = g["index"]
+    h = S.trace_closest(o[sel], d[sel])
+    assert np.array_equal(h["t"], g["t"]) and np.array_equal(h["prim"], g["prim"]) and np.array_equal(h["inst"], g["inst"])
+    assert int((g["inst"] != abi.INVALID_ID).sum()) > 10000
+    assert int(((g["prim"] == abi.INVALID_ID) & (g["inst"] != abi.INVALID_ID)).sum()) > 50  # analytic spheres are in view
+
+
+def test_golden_box_render():
+    g = np.load(os.path.join(GOLDEN, "box_render_48x36_g4_m4_seed11.npz"))
+    sc, cam_m, yfov = scenes.box_scene()
+    S = oracle.OracleScene(sc)
+    cam = oracle.camera_from_transform(scenes.x_fov_degrees(yfov, 48 / 36), cam_m)
+    st = abi.make_settings(48, 36, geometry_aa=4, material_aa=4, seed=11)
+    img, stats = S.render(cam, st)
+    assert np.array_equal(img, g["image"])  # counter-based RNG: independent of the thread count
+    assert [stats.primary_rays, stats.extension_rays, stats.shadow_rays] == list(g["rays"])
+    assert img.min() >= 0 and np.isfinite(img).all() and img.mean() > 0.05
+
+
+def test_render_tile_equals_crop_of_full_frame():
+    """Renderer::render only writes inside the tile and a pixel's value does not depend on the tile."""
+    sc, cam_m, yfov = scenes.box_scene()
+    S = oracle.OracleScene(sc)
+    cam = oracle.camera_from_transform(scenes.x_fov_degrees(yfov, 32 / 24), cam_m)
+    full, _ = S.render(cam, abi.make_settings(32, 24, geometry_aa=2, material_aa=2, seed=3))
+    part, _ = S.render(cam, abi.make_settings(32, 24, geometry_aa=2, material_aa=2, seed=3, tile=(8, 4, 20, 16)))
+    assert np.array_equal(part[4:16, 8:20], full[4:16, 8:20])
+    mask = np.ones((24, 32), bool)
+    mask[4:16, 8:20] = False
+    assert np.all(part[mask] == 0)
