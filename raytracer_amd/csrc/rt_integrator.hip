@@ -118,7 +118,7 @@ __device__ __forceinline__ TraceResult trace_closest_any_mode(const SceneView& s
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
 {
-    __shared__ int stack[kStackDepth][64];
+    __shared__ int stack[kLdsStack][64];
     const int lane = threadIdx.x;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint32_t s = blockIdx.x * 64u + lane;
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uint32_t n)
 {
-    __shared__ int stack[kStackDepth][64];
+    __shared__ int stack[kLdsStack][64];
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x * 64u + lane;
     if (q >= n) return;
@@ -467,7 +467,7 @@ __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uin
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ queue, uint32_t n)
 {
-    __shared__ int stack[kStackDepth][64];
+    __shared__ int stack[kLdsStack][64];
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x * 64u + lane;
     if (q >= n) return;

@@ -5,36 +5,41 @@
 // finished wave at once), one ray per lane, grid = ceil(n / 64).
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
 #include "rt_rng_inl.h"
 #include "rt_trace_inl.h"
 
 namespace rt {
 
-template <bool INSTANCED, bool COUNT>
-__global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const float* __restrict__ ro,
-                                                           const float* __restrict__ rd, uint64_t n,
-                                                           rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
+template <bool INSTANCED, bool COUNT, int BLOCK, bool PERSIST>
+__global__ __launch_bounds__(BLOCK) void trace_closest_kernel(SceneView sv, const float* __restrict__ ro,
+                                                              const float* __restrict__ rd, uint64_t n,
+                                                              rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
 {
-    __shared__ int stack[kStackDepth][64];
-    const int lane = threadIdx.x;
-    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
-    if (i >= n) return;
-    F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
-    F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-    uint32_t nb = 0, nt = 0;
-    TraceResult r;
-    if (INSTANCED && sv.refTop) r = trace_ray_reftop_closest<COUNT>(sv, o, d, stack, lane, nb, nt);
-    else r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
-    rtgpu_hit h;
-    h.t = r.t;
-    h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
-    h.inst = r.inst;
-    h.beta = r.beta;
-    h.gamma = r.gamma;
-    out[i] = h;
-    if (COUNT) {
-        counts[2 * i] = nb;
-        counts[2 * i + 1] = nt;
+    __shared__ int stackAll[BLOCK / 64][kLdsStack][64];
+    const int lane = threadIdx.x & 63;
+    int (*stack)[64] = stackAll[threadIdx.x >> 6];
+    const uint64_t stride = PERSIST ? (uint64_t)gridDim.x * BLOCK : 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
+        F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+        F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+        uint32_t nb = 0, nt = 0;
+        TraceResult r;
+        if (INSTANCED && sv.refTop) r = trace_ray_reftop_closest<COUNT>(sv, o, d, stack, lane, nb, nt);
+        else r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
+        rtgpu_hit h;
+        h.t = r.t;
+        h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
+        h.inst = r.inst;
+        h.beta = r.beta;
+        h.gamma = r.gamma;
+        out[i] = h;
+        if (COUNT) {
+            counts[2 * i] = nb;
+            counts[2 * i + 1] = nt;
+        }
+        if (!PERSIST) break;
     }
 }
 
@@ -43,7 +48,7 @@ __global__ __launch_bounds__(64) void trace_any_kernel(SceneView sv, const float
                                                        const float* __restrict__ rd, const float* __restrict__ tmax,
                                                        uint64_t n, uint8_t* __restrict__ occ)
 {
-    __shared__ int stack[kStackDepth][64];
+    __shared__ int stack[kLdsStack][64];
     const int lane = threadIdx.x;
     const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
     if (i >= n) return;
@@ -70,19 +75,41 @@ __global__ __launch_bounds__(256) void generate_primary_kernel(rtgpu_camera cam,
     rd[3 * k] = d.x; rd[3 * k + 1] = d.y; rd[3 * k + 2] = d.z;
 }
 
+static int env_int(const char* name, int def)
+{
+    const char* e = getenv(name);
+    return e ? atoi(e) : def;
+}
+
 hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const float* dD, uint64_t n,
                                 rtgpu_hit* dHits, uint32_t* dCounts, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
+    if (sv.singleMesh && !dCounts && variant != 0) {
+        if (variant == 1) { // 256-thread blocks
+            dim3 grid((unsigned)((n + 255) / 256)), block(256);
+            hipLaunchKernelGGL((trace_closest_kernel<false, false, 256, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        } else if (variant == 2) { // persistent waves
+            const int waves = env_int("RTGPU_TRACE_WAVES", 256 * 20);
+            dim3 grid((unsigned)waves), block(64);
+            hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        } else { // persistent 256-thread blocks
+            const int blocks = env_int("RTGPU_TRACE_WAVES", 256 * 5);
+            dim3 grid((unsigned)blocks), block(256);
+            hipLaunchKernelGGL((trace_closest_kernel<false, false, 256, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        }
+        return hipGetLastError();
+    }
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
     if (sv.singleMesh) {
-        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
     } else {
-        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<true, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_kernel<true, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<true, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<true, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
     }
     return hipGetLastError();
 }

@@ -168,11 +168,20 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
     F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
     const F3 winv = inv;
 
+    // The stack's first kLdsStack entries live in LDS (stack[entry][lane]: conflict-free), deeper
+    // ones -- rarely reached -- in per-lane private memory.
+    int spill[kStackDepth - kLdsStack];
+    auto push = [&](int v) {
+        if (sp < kLdsStack) stack[sp][lane] = v;
+        else spill[sp - kLdsStack] = v;
+        ++sp;
+    };
     // Pops the next pending subtree; leaves a mesh tree when its sentinel surfaces.  False = done.
     auto pop = [&]() -> bool {
         for (;;) {
             if (sp == 0) return false;
-            cur = stack[--sp][lane];
+            --sp;
+            cur = sp < kLdsStack ? stack[sp][lane] : spill[sp - kLdsStack];
             if (INSTANCED && cur == kSentinel) {
                 inMesh = false;
                 o = wo; d = wd; inv = winv;
@@ -199,8 +208,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
             if (ha && hb) {
                 const bool aFirst = t0a <= t0b;
                 cur = aFirst ? ca : cb;
-                stack[sp][lane] = aFirst ? cb : ca;
-                ++sp;
+                push(aFirst ? cb : ca);
             } else if (ha) {
                 cur = ca;
             } else if (hb) {
@@ -241,8 +249,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
             nodeBase = in.root;
             triBase = in.triBase;
             inMesh = true;
-            stack[sp][lane] = kSentinel;
-            ++sp;
+            push(kSentinel);
             cur = 0;
             continue;
         }

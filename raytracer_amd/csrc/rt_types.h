@@ -21,7 +21,8 @@
 
 namespace rt {
 
-constexpr int kStackDepth = 32;      // per-lane traversal stack entries (LDS)
+constexpr int kStackDepth = 32;      // per-lane traversal stack entries: the first kLdsStack in LDS, the rest in private memory
+constexpr int kLdsStack = 16;        // 16 x 64 lanes x 4 B = 4 KB of LDS per wave (does not limit occupancy); deeper entries are rare
 constexpr int kMaxTreeDepth = 30;    // builder guarantee per tree (top tree + mesh tree share the stack)
 constexpr int kMaxLeafHard = 16;     // leaf size field is 4 bits
 constexpr uint32_t kInvalid = 0xFFFFFFFFu;

@@ -56,6 +56,14 @@ def test_header_is_plain_c():
         subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Werror", "-I", os.path.join(ROOT, "include"), c, "-o", os.path.join(td, "x")])
 
 
+def test_cpp_adapter_compiles():
+    """include/rtgpu_adapter.hpp (the Renderer::render / Scene::traceRay shaped C++ front end)."""
+    with tempfile.TemporaryDirectory() as td:
+        c = os.path.join(td, "a.cpp")
+        open(c, "w").write('#include "rtgpu_adapter.hpp"\nint main(){ rtgpu::RenderSettings s; return s.geometryAAModifier - 4; }\n')
+        subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), c])
+
+
 def test_argument_errors_without_a_gpu():
     """Argument checks happen before any device work: same failure classes as the reference
     (std::invalid_argument -> ValueError)."""
