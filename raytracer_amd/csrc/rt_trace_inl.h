@@ -38,6 +38,8 @@ __device__ __forceinline__ float min_ref(float a, float b) { return (b < a) ? b 
 
 // AABB::getIntersections (shape/AABB.h:67-121) with 1/d hoisted out of the per-box work (the
 // reference divides per box; the quotient is the same value).  Returns hit and the clamped entry.
+// Exact restatement: used where box tests decide results (top-level trees with the reference's
+// non-conservative sphere boxes).
 __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                           F3 o, F3 inv, float& t0)
 {
@@ -51,6 +53,25 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
     float b = min_ref(min_ref(txmax, tymax), tzmax);
     t0 = max_ref(0.0f, a);
     return a <= b;
+}
+
+// Slab test for trees whose boxes are conservative (every mesh tree: triangle boxes are padded by
+// 1e-4, shape/TriangleMesh.cpp:177-191; and the library's own top-level tree over such meshes).
+// There the box test only prunes -- the closest hit is the same whatever tree and whatever box
+// arithmetic is used, as long as no box containing a hit is rejected -- so it is written for
+// speed: v_min/v_max (which drop a NaN operand: a 0*inf slab then counts as passed, never as a
+// rejection) and, unlike the reference (which accepts boxes that lie entirely behind the ray
+// origin), boxes whose exit distance is negative are skipped: they cannot contain a hit with t >= 0.
+__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
+                                          F3 o, F3 inv, float tlimit, float& t0)
+{
+    const float tx1 = (lox - o.x) * inv.x, tx2 = (hix - o.x) * inv.x;
+    const float ty1 = (loy - o.y) * inv.y, ty2 = (hiy - o.y) * inv.y;
+    const float tz1 = (loz - o.z) * inv.z, tz2 = (hiz - o.z) * inv.z;
+    const float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.0f));
+    const float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), tlimit));
+    t0 = tnear;
+    return tnear <= tfar;
 }
 
 // Triangle::intersect (math/Triangle.h:34-101) on a TriRec.  c0..c2 are the cofactors
@@ -145,6 +166,13 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
     best.beta = 0.0f;
     best.gamma = 0.0f;
 
+    // A ray with a NaN component finds nothing in the reference (every box comparison is false);
+    // the pruning-only slab test below would instead let it through, so it is answered here.
+    if (!((wo.x + wo.y + wo.z) + (wd.x + wd.y + wd.z) == (wo.x + wo.y + wo.z) + (wd.x + wd.y + wd.z))) {
+        if (!ANY) best.t = INFINITY;
+        return best;
+    }
+
     F3 o = wo, d = wd;
     uint32_t nodeBase, triBase = 0, curInst = 0;
     int cur;
@@ -181,7 +209,9 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
         for (;;) {
             if (sp == 0) return false;
             --sp;
-            cur = sp < kLdsStack ? stack[sp][lane] : spill[sp - kLdsStack];
+            cur = stack[sp < kLdsStack ? sp : 0][lane];            // always an LDS read ...
+            asm volatile("" : "+v"(cur));                          // (keeps the two loads apart: merged, they become one slow generic-address load)
+            if (sp >= kLdsStack) cur = spill[sp - kLdsStack];      // ... replaced by the private entry when that deep
             if (INSTANCED && cur == kSentinel) {
                 inMesh = false;
                 o = wo; d = wd; inv = winv;
@@ -200,10 +230,8 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             if (COUNT) nBoxes += 2;
             float t0a, t0b;
-            bool ha = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, t0a);
-            bool hb = slab_test(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, t0b);
-            ha = ha && t0a <= best.t;
-            hb = hb && t0b <= best.t;
+            const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, best.t, t0a);
+            const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, best.t, t0b);
             const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
             if (ha && hb) {
                 const bool aFirst = t0a <= t0b;
