@@ -5,6 +5,7 @@
 #include <array>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <thread>
@@ -351,7 +352,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         info.n_leaves += top.leafCount;
         info.max_depth = top.maxDepth + 1 + info.max_depth;
     }
-    if (nodes.size() >= (1ull << 31)) return fail(RTGPU_ERR_LIMIT, "more than 2^31 tree nodes");
+    if (nodes.size() * sizeof(Node64) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "tree nodes exceed 4 GiB (2^26 nodes)");
+    if (tris.size() * sizeof(TriRec) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "triangle records exceed 4 GiB (89 M triangles)");
     info.n_nodes = nodes.size();
     for (uint32_t i = 0; i < nInst; ++i) {
         if (inst[i].shape >= 0) {
@@ -414,6 +416,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.topRoot = topRoot;
     v.singleMesh = singleMesh ? 1u : 0u;
     v.refTop = refTop ? 1u : 0u;
+    v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 1;
     v.refTopRoot = (refTop && rtop.rootIsLeaf) ? encode_top_leaf(0, nInst) : 0;
     v.nMaterials = desc->n_materials;
     v.nPointLights = desc->n_point_lights;

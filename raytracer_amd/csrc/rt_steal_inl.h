@@ -1,0 +1,195 @@
+// rt_steal_inl.h -- wave-cooperative traversal with work stealing through the LDS stacks.
+//
+// A ray's traversal is a chain of dependent fetches, and a few rays (grazing the surface) need
+// 10-25x the average number of steps: with one lane per ray the slowest ray of a launch sets
+// the launch time while its 63 neighbour lanes -- and most of the chip -- idle.  Here a lane is a
+// *worker*: whenever some lanes of the wave have run out of work they take pending subtrees from
+// the bottom (oldest = largest) end of busy lanes' stacks, which live in LDS as
+// stack[entry][lane] and are therefore readable by every lane of the wave.  Several workers can
+// then be inside one ray's tree at once; they share the ray's best hit through an LDS word per
+// ray:
+//
+//   best[ray] = (float bits of t) << 32 | caller's triangle index      (64-bit atomic min in LDS)
+//
+// Non-negative floats order like their bit patterns, so the atomic min keeps the smallest t and,
+// among equal t, the smallest triangle index -- exactly the tree-independent result definition of
+// trace_ray(), whatever the schedule.  The upper half is also every worker's pruning distance.
+// The payload (leaf slot, beta, gamma) is written by the lane whose value is the minimum when it
+// re-reads the word after its atomic; a later, smaller hit overwrites it in program order.
+//
+// Single-mesh scenes only (the benchmark and render workloads are triangle soups); instanced
+// scenes use trace_ray().
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_trace_inl.h"
+
+namespace rt {
+
+struct StealLds {
+    int stack[kLdsStack][64];
+    unsigned long long best[64];
+    uint32_t paySlot[64];
+    float payBeta[64];
+    float payGamma[64];
+    int giveList[64];
+    uint32_t cnt[2][64];
+};
+
+
+__device__ __forceinline__ unsigned long long pack_hit(float t, uint32_t id)
+{
+    return ((unsigned long long)__float_as_uint(t) << 32) | id;
+}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, bool hasRay, F3 wo, F3 wd, float tmax,
+                                                        StealLds& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
+                                                        const int minIdle = 1)
+{
+    const DevInstance& in = sv.inst[0];
+    const uint32_t nodeBase = in.root, triBase = in.triBase;
+    F3 o = xf_point_inv(in.inv, wo), d = xf_vector_inv(in.inv, wd);
+    // rays with a NaN component find nothing (see trace_ray)
+    const bool valid = hasRay && ((wo.x + wo.y + wo.z) + (wd.x + wd.y + wd.z) == (wo.x + wo.y + wo.z) + (wd.x + wd.y + wd.z));
+    F3 inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+
+    L.best[lane] = pack_hit(ANY ? tmax : INFINITY, kInvalid);
+    L.paySlot[lane] = kInvalid;
+    L.payBeta[lane] = 0.0f;
+    L.payGamma[lane] = 0.0f;
+    if (COUNT) { L.cnt[0][lane] = 0; L.cnt[1][lane] = 0; }
+
+    int owner = lane;          // the ray this worker is traversing for
+    int cur = 0;
+    int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp); thieves take from sb
+    bool busy = valid;
+    float tlim = ANY ? tmax : INFINITY;
+    float rtmax = tmax;        // any-hit: the limit of the ray this worker is traversing for
+    uint32_t wb = 0, wt = 0;
+    int spill[kStackDepth - kLdsStack];
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+
+    for (;;) {
+        // ---- steal phase (all lanes converged here) ----------------------------------------------
+        const unsigned long long idleMask = __ballot(!busy);
+        if (idleMask == ~0ull) break;
+        if (__popcll(idleMask) >= minIdle) {
+            const bool canGive = busy && sb < sp && sb < kLdsStack;
+            const unsigned long long giveMask = __ballot(canGive);
+            if (giveMask != 0ull) {
+                const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
+                const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
+                if (canGive) L.giveList[rg] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool thief = !busy && ri < nGive;
+                const int v = L.giveList[thief ? ri : 0];
+                const int vsb = __shfl(sb, v, 64);
+                const int vowner = __shfl(owner, v, 64);
+                const float vox = __shfl(o.x, v, 64), voy = __shfl(o.y, v, 64), voz = __shfl(o.z, v, 64);
+                const float vdx = __shfl(d.x, v, 64), vdy = __shfl(d.y, v, 64), vdz = __shfl(d.z, v, 64);
+                const float vix = __shfl(inv.x, v, 64), viy = __shfl(inv.y, v, 64), viz = __shfl(inv.z, v, 64);
+                const float vtmax = __shfl(rtmax, v, 64);
+                if (thief) {
+                    cur = L.stack[vsb][v];
+                    owner = vowner;
+                    o = f3(vox, voy, voz); d = f3(vdx, vdy, vdz); inv = f3(vix, viy, viz);
+                    rtmax = vtmax;
+                    sp = 0; sb = 0;
+                    busy = true;
+                    tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
+                }
+                if (canGive && rg < nIdle) ++sb;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        if (!busy) continue;
+
+        // ---- inner nodes ---------------------------------------------------------------------------
+        bool alive = true;
+        while (cur >= 0) {
+            const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
+            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+            if (COUNT) wb += 2;
+            float t0a, t0b;
+            const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
+            const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
+            const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+            if (ha && hb) {
+                const bool aFirst = t0a <= t0b;
+                cur = aFirst ? ca : cb;
+                const int far = aFirst ? cb : ca;
+                if (sp < kLdsStack) L.stack[sp][lane] = far;
+                else spill[sp - kLdsStack] = far;
+                ++sp;
+            } else if (ha) {
+                cur = ca;
+            } else if (hb) {
+                cur = cb;
+            } else {
+                if (sp == sb) { alive = false; break; }
+                --sp;
+                cur = L.stack[sp < kLdsStack ? sp : 0][lane];
+                asm volatile("" : "+v"(cur));
+                if (sp >= kLdsStack) cur = spill[sp - kLdsStack];
+            }
+        }
+        if (alive) {
+            // ---- triangle leaf -----------------------------------------------------------------------
+            const uint32_t leaf = (uint32_t)(~cur);
+            const uint32_t first = leaf >> 4, count = (leaf & 15u) + 1u;
+            for (uint32_t k = 0; k < count; ++k) {
+                const uint32_t slot = triBase + first + k;
+                const float4* tp = tri_ptr(sv, slot);
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                float t, be, ga;
+                if (COUNT) wt += 1;
+                if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
+                    if (ANY) {
+                        if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
+                    } else if (t <= tlim) {
+                        const unsigned long long mine = pack_hit(t, sv.triIds[slot]);
+                        const unsigned long long old = atomicMin(&L.best[owner], mine);
+                        if (mine < old && L.best[owner] == mine) {
+                            L.paySlot[owner] = slot; L.payBeta[owner] = be; L.payGamma[owner] = ga;
+                        }
+                    }
+                }
+            }
+            tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
+            if ((ANY && tlim == 0.0f && L.best[owner] == 0ull) || sp == sb) {
+                alive = false;
+            } else {
+                --sp;
+                cur = L.stack[sp < kLdsStack ? sp : 0][lane];
+                asm volatile("" : "+v"(cur));
+                if (sp >= kLdsStack) cur = spill[sp - kLdsStack];
+            }
+        }
+        if (!alive) {
+            busy = false;
+            sp = 0; sb = 0;
+            if (COUNT) { atomicAdd(&L.cnt[0][owner], wb); atomicAdd(&L.cnt[1][owner], wt); wb = 0; wt = 0; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TraceResult r;
+    const unsigned long long b = L.best[lane];
+    if (ANY) {
+        r.t = tmax; r.slot = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
+        r.inst = (b == 0ull && valid) ? 0u : kInvalid;
+    } else {
+        const bool hit = L.paySlot[lane] != kInvalid;
+        r.t = hit ? __uint_as_float((uint32_t)(b >> 32)) : INFINITY;
+        r.slot = L.paySlot[lane];
+        r.inst = hit ? 0u : kInvalid;
+        r.beta = L.payBeta[lane];
+        r.gamma = L.payGamma[lane];
+    }
+    if (COUNT) { nBoxes = L.cnt[0][lane]; nTris = L.cnt[1][lane]; }
+    return r;
+}
+
+} // namespace rt

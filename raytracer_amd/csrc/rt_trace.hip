@@ -8,6 +8,7 @@
 #include <cstdlib>
 
 #include "rt_rng_inl.h"
+#include "rt_steal_inl.h"
 #include "rt_trace_inl.h"
 
 namespace rt {
@@ -41,6 +42,51 @@ __global__ __launch_bounds__(BLOCK) void trace_closest_kernel(SceneView sv, cons
         }
         if (!PERSIST) break;
     }
+}
+
+// Single-mesh scenes: wave-cooperative traversal with work stealing (rt_steal_inl.h).
+template <bool COUNT>
+__global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, const float* __restrict__ ro,
+                                                                 const float* __restrict__ rd, uint64_t n,
+                                                                 rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
+{
+    __shared__ StealLds lds;
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    const bool has = i < n;
+    const uint64_t j = has ? i : 0;
+    const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
+    const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
+    uint32_t nb = 0, nt = 0;
+    const TraceResult r = trace_wave_steal<false, COUNT>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle);
+    if (!has) return;
+    rtgpu_hit h;
+    h.t = r.t;
+    h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
+    h.inst = r.inst;
+    h.beta = r.beta;
+    h.gamma = r.gamma;
+    out[i] = h;
+    if (COUNT) {
+        counts[2 * i] = nb;
+        counts[2 * i + 1] = nt;
+    }
+}
+
+__global__ __launch_bounds__(64) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
+                                                             const float* __restrict__ rd, const float* __restrict__ tmax,
+                                                             uint64_t n, uint8_t* __restrict__ occ)
+{
+    __shared__ StealLds lds;
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + lane;
+    const bool has = i < n;
+    const uint64_t j = has ? i : 0;
+    const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
+    const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
+    uint32_t nb = 0, nt = 0;
+    const TraceResult r = trace_wave_steal<true, false>(sv, has, o, d, tmax[j], lds, lane, nb, nt, sv.stealMinIdle);
+    if (has) occ[i] = r.inst != kInvalid ? 1 : 0;
 }
 
 template <bool INSTANCED>
@@ -86,7 +132,7 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
 {
     if (n == 0) return hipSuccess;
     static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
-    if (sv.singleMesh && !dCounts && variant != 0) {
+    if (sv.singleMesh && !dCounts && variant > 0) {
         if (variant == 1) { // 256-thread blocks
             dim3 grid((unsigned)((n + 255) / 256)), block(256);
             hipLaunchKernelGGL((trace_closest_kernel<false, false, 256, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
@@ -104,6 +150,11 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
+    if (sv.singleMesh && variant != -1) {
+        if (dCounts) hipLaunchKernelGGL((trace_closest_steal_kernel<true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        return hipGetLastError();
+    }
     if (sv.singleMesh) {
         if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
         else hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
@@ -121,7 +172,9 @@ hipError_t launch_trace_any(const SceneView& sv, const float* dO, const float* d
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
-    if (sv.singleMesh) hipLaunchKernelGGL((trace_any_kernel<false>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
+    static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
+    if (sv.singleMesh && variant != -1) hipLaunchKernelGGL(trace_any_steal_kernel, grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
+    else if (sv.singleMesh) hipLaunchKernelGGL((trace_any_kernel<false>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     else hipLaunchKernelGGL((trace_any_kernel<true>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     return hipGetLastError();
 }

@@ -65,6 +65,9 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
 __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
                                           F3 o, F3 inv, float tlimit, float& t0)
 {
+    // (plane - o) * (1/d) like the reference: subtracting first keeps the error relative to the
+    // result.  (fma(plane, 1/d, -o/d) would save instructions but cancels catastrophically for rays
+    // nearly parallel to an axis and then rejects boxes that contain hits.)
     const float tx1 = (lox - o.x) * inv.x, tx2 = (hix - o.x) * inv.x;
     const float ty1 = (loy - o.y) * inv.y, ty2 = (hiy - o.y) * inv.y;
     const float tz1 = (loz - o.z) * inv.z, tz2 = (hiz - o.z) * inv.z;
@@ -133,6 +136,18 @@ __device__ __forceinline__ F3 xf_vector_inv(const double* m, F3 p)
     return F3{(float)(((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 0.0),
               (float)(((m[4] * x + m[5] * y) + m[6] * z) + m[7] * 0.0),
               (float)(((m[8] * x + m[9] * y) + m[10] * z) + m[11] * 0.0)};
+}
+
+// Node / triangle records are addressed with 32-bit byte offsets from the array base (one scalar
+// base + one vector offset per fetch instead of 64-bit vector address arithmetic); scene creation
+// checks that both arrays are smaller than 4 GiB.
+__device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t node)
+{
+    return (const float4*)((const char*)sv.nodes + (node << 6));
+}
+__device__ __forceinline__ const float4* tri_ptr(const SceneView& sv, uint32_t slot)
+{
+    return (const float4*)((const char*)sv.tris + slot * 48u);
 }
 
 struct TraceResult {
@@ -226,7 +241,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
     while (alive) {
         // ---- inner nodes: one 64-byte record holds both child boxes -----------------------
         while (cur >= 0) {
-            const float4* np = sv.nodes + ((size_t)(nodeBase + (uint32_t)cur) << 2);
+            const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             if (COUNT) nBoxes += 2;
             float t0a, t0b;
@@ -284,7 +299,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
         // triangle leaf (TriangleMesh::intersect / testVisibility, shape/TriangleMesh.cpp:99-175)
         for (uint32_t k = 0; k < count; ++k) {
             const uint32_t slot = triBase + first + k;
-            const float4* tp = sv.tris + (size_t)slot * 3;
+            const float4* tp = tri_ptr(sv, slot);
             const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
             float t, be, ga;
             if (COUNT) nTris += 1;
