@@ -36,6 +36,7 @@
 
 #include "rt_scene.h"
 #include "rt_shade_inl.h"
+#include "rt_steal_inl.h"
 
 namespace rt {
 
@@ -106,29 +107,63 @@ __device__ __forceinline__ void queue_push(uint32_t* queue, uint32_t* counter, b
     }
 }
 
+// Per-wave LDS of a traversal kernel: the work-stealing state for single-mesh scenes, the plain
+// per-lane stack otherwise.
 template <bool INSTANCED>
-__device__ __forceinline__ TraceResult trace_closest_any_mode(const SceneView& sv, F3 o, F3 d, int (*stack)[64], int lane)
+struct TraceLds {
+    struct Plain { int stack[kLdsStack][64]; };
+    using type = Plain;
+};
+template <>
+struct TraceLds<false> {
+    using type = StealLds;
+};
+
+// Closest hit for the wave's rays (every lane calls; lanes without a ray pass has = false).
+template <bool INSTANCED>
+__device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool has, F3 o, F3 d, typename TraceLds<INSTANCED>::type& lds, int lane)
 {
     uint32_t nb = 0, nt = 0;
-    if (INSTANCED && sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, stack, lane, nb, nt);
-    return trace_ray<INSTANCED, false, false>(sv, o, d, INFINITY, stack, lane, nb, nt);
+    if constexpr (!INSTANCED) {
+        return trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle);
+    } else {
+        TraceResult r;
+        r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
+        if (!has) return r;
+        if (sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, lds.stack, lane, nb, nt);
+        return trace_ray<true, false, false>(sv, o, d, INFINITY, lds.stack, lane, nb, nt);
+    }
+}
+template <bool INSTANCED>
+__device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3 d, float tmax, typename TraceLds<INSTANCED>::type& lds, int lane)
+{
+    uint32_t nb = 0, nt = 0;
+    if constexpr (!INSTANCED) {
+        return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle).inst != kInvalid;
+    } else {
+        if (!has) return false;
+        if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);
+        return trace_ray<true, true, false>(sv, o, d, tmax, lds.stack, lane, nb, nt).inst != kInvalid;
+    }
 }
 
 // ---- primary ---------------------------------------------------------------------------------
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
 {
-    __shared__ int stack[kLdsStack][64];
+    __shared__ typename TraceLds<INSTANCED>::type lds;
     const int lane = threadIdx.x;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
-    const uint32_t s = blockIdx.x * 64u + lane;
-    if (s >= batch.nPixels * G) return;
+    const uint32_t s0 = blockIdx.x * 64u + lane;
+    const bool has = s0 < batch.nPixels * G;
+    const uint32_t s = has ? s0 : 0u;
     const uint32_t pl = s / G, i = s % G;
     int x, y;
     tile_pixel(st, batch.pixelStart + pl, x, y);
     F3 o, d;
     camera_ray(cam, st, x, y, (int)i, o, d);
-    const TraceResult r = trace_closest_any_mode<INSTANCED>(sv, o, d, stack, lane);
+    const TraceResult r = wave_closest<INSTANCED>(sv, has, o, d, lds, lane);
+    if (!has) return;
     const bool hit = r.inst != kInvalid;
 
     float* res0 = pool.result + (size_t)s * M * 3;
@@ -441,22 +476,16 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uint32_t n)
 {
-    __shared__ int stack[kLdsStack][64];
+    __shared__ typename TraceLds<INSTANCED>::type lds;
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x * 64u + lane;
-    if (q >= n) return;
-    const uint32_t p = pool.qShadow[q];
+    const bool has = q < n;
+    const uint32_t p = pool.qShadow[has ? q : 0u];
     const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
     const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
     const float tmax = pool.tmax[p];
-    bool occluded;
-    if (INSTANCED && sv.refTop) {
-        occluded = trace_ray_reftop_any(sv, o, d, tmax, stack, lane);
-    } else {
-        uint32_t nb = 0, nt = 0;
-        occluded = trace_ray<INSTANCED, true, false>(sv, o, d, tmax, stack, lane, nb, nt).inst != kInvalid;
-    }
-    if (!occluded) {
+    const bool occluded = wave_any<INSTANCED>(sv, has, o, d, tmax, lds, lane);
+    if (has && !occluded) {
         pool.result[3 * (size_t)p] = pool.contrib[3 * (size_t)p];
         pool.result[3 * (size_t)p + 1] = pool.contrib[3 * (size_t)p + 1];
         pool.result[3 * (size_t)p + 2] = pool.contrib[3 * (size_t)p + 2];
@@ -467,14 +496,15 @@ __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uin
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ queue, uint32_t n)
 {
-    __shared__ int stack[kLdsStack][64];
+    __shared__ typename TraceLds<INSTANCED>::type lds;
     const int lane = threadIdx.x;
     const uint32_t q = blockIdx.x * 64u + lane;
-    if (q >= n) return;
-    const uint32_t p = queue[q];
+    const bool has = q < n;
+    const uint32_t p = queue[has ? q : 0u];
     const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
     const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
-    const TraceResult r = trace_closest_any_mode<INSTANCED>(sv, o, d, stack, lane);
+    const TraceResult r = wave_closest<INSTANCED>(sv, has, o, d, lds, lane);
+    if (!has) return;
     pool.hitT[p] = r.t; pool.hitSlot[p] = r.slot; pool.hitInst[p] = r.inst; pool.hitBeta[p] = r.beta; pool.hitGamma[p] = r.gamma;
 }
 
