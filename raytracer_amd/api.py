@@ -19,7 +19,7 @@ import numpy as np
 from . import abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "librtgpu.so")
+LIB_PATH = os.environ.get("RTGPU_LIB") or os.path.join(_HERE, "librtgpu.so")
 
 EXPORTS = [
     "rtgpu_last_error", "rtgpu_device_count", "rtgpu_set_device", "rtgpu_scene_create", "rtgpu_scene_destroy",

@@ -297,6 +297,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         BuildParams bp;
         bp.threads = threads;
         bp.maxDepth = meshDepthBudget;
+        if (const char* e = std::getenv("RTGPU_BUILD_MAX_LEAF")) bp.maxLeaf = std::max(1, std::min(std::atoi(e), (int)kMaxLeafHard));
+        if (const char* e = std::getenv("RTGPU_BUILD_TRAVERSAL_COST")) bp.traversalCost = (float)std::atof(e);
         const int need = ceil_log2((md.n_triangles + kMaxLeafHard - 1) / kMaxLeafHard);
         if (need > meshDepthBudget) return fail(RTGPU_ERR_LIMIT, "scene too deep for the traversal stack");
         BuiltTree bt = build_tree(primBoxes[m].data(), md.n_triangles, bp);
@@ -417,6 +419,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.singleMesh = singleMesh ? 1u : 0u;
     v.refTop = refTop ? 1u : 0u;
     v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 1;
+    v.stealLeafPct = std::getenv("RTGPU_STEAL_LEAF_PCT") ? std::atoi(std::getenv("RTGPU_STEAL_LEAF_PCT")) : 48;
     v.refTopRoot = (refTop && rtop.rootIsLeaf) ? encode_top_leaf(0, nInst) : 0;
     v.nMaterials = desc->n_materials;
     v.nPointLights = desc->n_point_lights;

@@ -125,7 +125,7 @@ __device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool ha
 {
     uint32_t nb = 0, nt = 0;
     if constexpr (!INSTANCED) {
-        return trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle);
+        return trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     } else {
         TraceResult r;
         r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
@@ -139,7 +139,7 @@ __device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3
 {
     uint32_t nb = 0, nt = 0;
     if constexpr (!INSTANCED) {
-        return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle).inst != kInvalid;
+        return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
     } else {
         if (!has) return false;
         if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);

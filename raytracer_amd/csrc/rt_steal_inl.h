@@ -45,7 +45,7 @@ __device__ __forceinline__ unsigned long long pack_hit(float t, uint32_t id)
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, bool hasRay, F3 wo, F3 wd, float tmax,
                                                         StealLds& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
-                                                        const int minIdle = 1)
+                                                        const int minIdle = 1, const int leafPct = 48)
 {
     const DevInstance& in = sv.inst[0];
     const uint32_t nodeBase = in.root, triBase = in.triBase;
@@ -69,11 +69,21 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
     uint32_t wb = 0, wt = 0;
     int spill[kStackDepth - kLdsStack];
     const unsigned long long ltMask = (1ull << lane) - 1ull;
+#ifdef RT_DEV_STATS
+    float dsOuter = 0, dsSteal = 0, dsNodeIt = 0, dsLeafIt = 0, dsBusy = 0, dsStolen = 0;
+#endif
 
+    // Every iteration the wave runs one step of one kind: a node step for the lanes standing at an
+    // inner node, or a leaf step for the lanes standing at a leaf.  Lanes of the other kind wait, so
+    // the kind is chosen per iteration: node steps as long as few lanes wait at leaves.
     for (;;) {
-        // ---- steal phase (all lanes converged here) ----------------------------------------------
-        const unsigned long long idleMask = __ballot(!busy);
-        if (idleMask == ~0ull) break;
+        const unsigned long long busyMask = __ballot(busy);
+        if (busyMask == 0ull) break;
+        const unsigned long long idleMask = ~busyMask;
+#ifdef RT_DEV_STATS
+        if (lane == 0) { dsOuter += 1; dsBusy += __popcll(busyMask); }
+#endif
+        // ---- steal phase -------------------------------------------------------------------------
         if (__popcll(idleMask) >= minIdle) {
             const bool canGive = busy && sb < sp && sb < kLdsStack;
             const unsigned long long giveMask = __ballot(canGive);
@@ -84,6 +94,9 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
                 const bool thief = !busy && ri < nGive;
+#ifdef RT_DEV_STATS
+                if (lane == 0) { dsSteal += 1; dsStolen += nGive < nIdle ? nGive : nIdle; }
+#endif
                 const int v = L.giveList[thief ? ri : 0];
                 const int vsb = __shfl(sb, v, 64);
                 const int vowner = __shfl(owner, v, 64);
@@ -104,38 +117,45 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        if (!busy) continue;
-
-        // ---- inner nodes ---------------------------------------------------------------------------
-        bool alive = true;
-        while (cur >= 0) {
-            const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) wb += 2;
-            float t0a, t0b;
-            const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
-            const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
-            const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
-            if (ha && hb) {
-                const bool aFirst = t0a <= t0b;
-                cur = aFirst ? ca : cb;
-                const int far = aFirst ? cb : ca;
-                if (sp < kLdsStack) L.stack[sp][lane] = far;
-                else spill[sp - kLdsStack] = far;
-                ++sp;
-            } else if (ha) {
-                cur = ca;
-            } else if (hb) {
-                cur = cb;
-            } else {
-                if (sp == sb) { alive = false; break; }
-                --sp;
-                cur = L.stack[sp < kLdsStack ? sp : 0][lane];
-                asm volatile("" : "+v"(cur));
-                if (sp >= kLdsStack) cur = spill[sp - kLdsStack];
+        const unsigned long long nowBusy = __ballot(busy);
+        const unsigned long long nodeMask = __ballot(busy && cur >= 0);
+        const int nBusy = __popcll(nowBusy), nNode = __popcll(nodeMask);
+        const bool nodeStep = nNode > 0 && (nBusy - nNode) * 128 < leafPct * nBusy;
+        bool done = false;
+        if (nodeStep) {
+            // ---- inner node ------------------------------------------------------------------------
+            if (busy && cur >= 0) {
+                const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                if (COUNT) wb += 2;
+#ifdef RT_DEV_STATS
+                dsNodeIt += 1.0f / (float)__popcll(__ballot(true));
+#endif
+                float t0a, t0b;
+                const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
+                const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
+                const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+                if (ha && hb) {
+                    const bool aFirst = t0a <= t0b;
+                    cur = aFirst ? ca : cb;
+                    const int far = aFirst ? cb : ca;
+                    if (sp < kLdsStack) L.stack[sp][lane] = far;
+                    else spill[sp - kLdsStack] = far;
+                    ++sp;
+                } else if (ha) {
+                    cur = ca;
+                } else if (hb) {
+                    cur = cb;
+                } else if (sp == sb) {
+                    done = true;
+                } else {
+                    --sp;
+                    cur = L.stack[sp < kLdsStack ? sp : 0][lane];
+                    asm volatile("" : "+v"(cur));
+                    if (sp >= kLdsStack) cur = spill[sp - kLdsStack];
+                }
             }
-        }
-        if (alive) {
+        } else if (busy && cur < 0) {
             // ---- triangle leaf -----------------------------------------------------------------------
             const uint32_t leaf = (uint32_t)(~cur);
             const uint32_t first = leaf >> 4, count = (leaf & 15u) + 1u;
@@ -145,6 +165,9 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
                 float t, be, ga;
                 if (COUNT) wt += 1;
+#ifdef RT_DEV_STATS
+                dsLeafIt += 1.0f / (float)__popcll(__ballot(true));
+#endif
                 if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
                     if (ANY) {
                         if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
@@ -159,7 +182,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
             }
             tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
             if ((ANY && tlim == 0.0f && L.best[owner] == 0ull) || sp == sb) {
-                alive = false;
+                done = true;
             } else {
                 --sp;
                 cur = L.stack[sp < kLdsStack ? sp : 0][lane];
@@ -167,7 +190,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 if (sp >= kLdsStack) cur = spill[sp - kLdsStack];
             }
         }
-        if (!alive) {
+        if (done) {
             busy = false;
             sp = 0; sb = 0;
             if (COUNT) { atomicAdd(&L.cnt[0][owner], wb); atomicAdd(&L.cnt[1][owner], wt); wb = 0; wt = 0; }
@@ -189,6 +212,18 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
         r.gamma = L.payGamma[lane];
     }
     if (COUNT) { nBoxes = L.cnt[0][lane]; nTris = L.cnt[1][lane]; }
+#ifdef RT_DEV_STATS
+    // developer build: lanes 0..5 report wave-level schedule statistics in place of their tri counts
+    if (COUNT) {
+        __shared__ float ds[8];
+        if (lane < 8) ds[lane] = 0.0f;
+        __builtin_amdgcn_wave_barrier();
+        atomicAdd(&ds[0], dsOuter); atomicAdd(&ds[1], dsSteal); atomicAdd(&ds[2], dsNodeIt);
+        atomicAdd(&ds[3], dsLeafIt); atomicAdd(&ds[4], dsBusy); atomicAdd(&ds[5], dsStolen);
+        __builtin_amdgcn_wave_barrier();
+        if (lane < 6) nTris = (uint32_t)(ds[lane] + 0.5f);
+    }
+#endif
     return r;
 }
 

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, c
     const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
     const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
     uint32_t nb = 0, nt = 0;
-    const TraceResult r = trace_wave_steal<false, COUNT>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle);
+    const TraceResult r = trace_wave_steal<false, COUNT>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     if (!has) return;
     rtgpu_hit h;
     h.t = r.t;
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(64) void trace_any_steal_kernel(SceneView sv, const
     const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
     const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
     uint32_t nb = 0, nt = 0;
-    const TraceResult r = trace_wave_steal<true, false>(sv, has, o, d, tmax[j], lds, lane, nb, nt, sv.stealMinIdle);
+    const TraceResult r = trace_wave_steal<true, false>(sv, has, o, d, tmax[j], lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     if (has) occ[i] = r.inst != kInvalid ? 1 : 0;
 }
 
