@@ -138,6 +138,21 @@ __device__ __forceinline__ F3 xf_vector_inv(const double* m, F3 p)
               (float)(((m[8] * x + m[9] * y) + m[10] * z) + m[11] * 0.0)};
 }
 
+// Both at once for a single-mesh scene.  With an identity transform the fp64 row sums reduce to
+// x + 0 per component (which also turns -0 into +0, like the sums do) as long as every component
+// is finite (0 * inf would make NaNs in the general form), so that case skips the fp64 arithmetic.
+__device__ __forceinline__ void xf_ray_inv(const double* m, bool identity, F3 wo, F3 wd, F3& o, F3& d)
+{
+    const float s = (wo.x + wo.y + wo.z) + (wd.x + wd.y + wd.z);
+    if (identity && (s - s) == 0.0f) {
+        o = f3(wo.x + 0.0f, wo.y + 0.0f, wo.z + 0.0f);
+        d = f3(wd.x + 0.0f, wd.y + 0.0f, wd.z + 0.0f);
+    } else {
+        o = xf_point_inv(m, wo);
+        d = xf_vector_inv(m, wd);
+    }
+}
+
 // Node / triangle records are addressed with 32-bit byte offsets from the array base (one scalar
 // base + one vector offset per fetch instead of 64-bit vector address arithmetic); scene creation
 // checks that both arrays are smaller than 4 GiB.
@@ -155,6 +170,7 @@ struct TraceResult {
     uint32_t slot;    // global leaf slot of the triangle, kInvalid for spheres / miss
     uint32_t inst;    // instance index, kInvalid on a miss
     float beta, gamma;
+    uint32_t prim;    // caller's triangle index; filled by trace_wave_queue() only
 };
 
 constexpr int kSentinel = 0x7FFFFFFF;
@@ -201,8 +217,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
         inMesh = false;
     } else {
         const DevInstance& in = sv.inst[soloInst];
-        o = xf_point_inv(in.inv, wo);
-        d = xf_vector_inv(in.inv, wd);
+        xf_ray_inv(in.inv, sv.identityXf != 0, wo, wd, o, d);
         nodeBase = in.root;
         triBase = in.triBase;
         cur = 0;
