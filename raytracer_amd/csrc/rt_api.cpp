@@ -143,7 +143,6 @@ void rtgpu_scene::release()
                           view.materials, view.pointLights, view.areaLights};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
-    if (view.queueCounters) (void)hipFree(view.queueCounters);
     view = rt::SceneView{};
 }
 
@@ -415,19 +414,6 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         delete sc;
         return rc;
     }
-    {
-        const size_t qbytes = (size_t)rt::kQueueRing * rt::kQueueCounters * 64 * sizeof(uint32_t);
-        void* qp = nullptr;
-        if (hipMalloc(&qp, qbytes) != hipSuccess || hipMemset(qp, 0, qbytes) != hipSuccess) {
-            if (qp) (void)hipFree(qp);
-            sc->release();
-            delete sc;
-            return fail(RTGPU_ERR_OUT_OF_MEMORY, "out of device memory (ray-queue counters)");
-        }
-        v.queueCounters = (uint32_t*)qp;
-        bytes += qbytes;
-    }
-    v.queueFetchMin = std::getenv("RTGPU_QUEUE_FETCH_MIN") ? std::max(1, std::min(64, std::atoi(std::getenv("RTGPU_QUEUE_FETCH_MIN")))) : 8;
     v.nInst = nInst;
     v.topRoot = topRoot;
     v.singleMesh = singleMesh ? 1u : 0u;

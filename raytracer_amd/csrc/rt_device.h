@@ -46,8 +46,6 @@ struct SceneView {
     int32_t refTopRoot;         // refTop: 0 (inner root) or the leaf reference when the whole list is one leaf
     int32_t stealMinIdle;       // idle lanes a wave needs before it runs a work-stealing round
     int32_t stealLeafPct;       // a wave runs a leaf step once this share (of 128) of its busy lanes waits at a leaf
-    uint32_t* queueCounters;    // kQueueRing blocks of kQueueCounters ray-queue counters (64 words apart) for persistent launches
-    int32_t queueFetchMin;      // idle lanes a persistent wave needs before it takes new rays
     // shade stage
     const float* vertNormals;   // per leaf slot: 3 vertex normals (9 floats)
     const uint32_t* triMaterial; // per leaf slot material id, or kInvalid -> instance material
@@ -58,9 +56,6 @@ struct SceneView {
     int32_t hasEnv;
     float envRadiance[3];
 };
-
-constexpr uint32_t kQueueRing = 16;       // launches that may be in flight at once on one scene
-constexpr uint32_t kQueueCounters = 32;   // ray-queue counters per launch
 
 // Closest hit for n rays (Scene::traceRay).  counts may be null.
 hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const float* dD, uint64_t n,

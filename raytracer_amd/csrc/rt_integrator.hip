@@ -116,7 +116,7 @@ struct TraceLds {
 };
 template <>
 struct TraceLds<false> {
-    using type = StealLds;
+    using type = StealLds<false>;
 };
 
 // Closest hit for the wave's rays (every lane calls; lanes without a ray pass has = false).
@@ -125,7 +125,9 @@ __device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool ha
 {
     uint32_t nb = 0, nt = 0;
     if constexpr (!INSTANCED) {
-        return trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+        TraceResult r = trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+        if (r.slot != kInvalid) hit_barycentrics(sv, r.slot, o, d, r.beta, r.gamma);
+        return r;
     } else {
         TraceResult r;
         r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;

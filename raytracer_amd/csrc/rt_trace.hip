@@ -6,7 +6,6 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
-#include <atomic>
 #include <cstdlib>
 
 #include "rt_rng_inl.h"
@@ -65,7 +64,7 @@ __global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, c
                                                                  const float* __restrict__ rd, uint64_t n, uint64_t nb8,
                                                                  rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
 {
-    __shared__ StealLds lds;
+    __shared__ StealLds<COUNT> lds;
     const int lane = threadIdx.x;
     const uint64_t i = interleave8((uint64_t)blockIdx.x * 64 + lane, nb8);
     const bool has = i < n;
@@ -77,10 +76,17 @@ __global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, c
     if (!has) return;
     rtgpu_hit h;
     h.t = r.t;
-    h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
+    h.prim = r.prim;
     h.inst = r.inst;
-    h.beta = r.beta;
-    h.gamma = r.gamma;
+    h.beta = 0.0f;
+    h.gamma = 0.0f;
+    if (r.slot != kInvalid) {
+        // the ray is read again rather than kept in registers across the traversal loop
+        const float* ro2 = ro;
+        const float* rd2 = rd;
+        asm volatile("" : "+s"(ro2), "+s"(rd2));
+        hit_barycentrics(sv, r.slot, f3(ro2[3 * i], ro2[3 * i + 1], ro2[3 * i + 2]), f3(rd2[3 * i], rd2[3 * i + 1], rd2[3 * i + 2]), h.beta, h.gamma);
+    }
     out[i] = h;
     if (COUNT) {
         counts[2 * i] = nb;
@@ -88,66 +94,11 @@ __global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, c
     }
 }
 
-// Single-mesh scenes, persistent waves: rays are taken from a queue (trace_wave_queue, rt_steal_inl.h).
-template <bool COUNT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void trace_closest_queue_kernel(SceneView sv, RayQueue q, uint64_t nb8, const float* __restrict__ ro,
-                                                                 const float* __restrict__ rd,
-                                                                 rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
-{
-    __shared__ QueueLds<COUNT> lds;
-    const int lane = threadIdx.x;
-    trace_wave_queue<false, COUNT>(
-        sv, q, lds, lane,
-        [&](uint32_t p, F3& o, F3& d, float& tmax) {
-            const size_t i = interleave8(p, nb8);
-            o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
-            d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-            tmax = INFINITY;
-        },
-        [&](uint32_t p, const TraceResult& r, uint32_t nb, uint32_t nt) {
-            const size_t i = interleave8(p, nb8);
-            rtgpu_hit h;
-            h.t = r.t;
-            h.prim = r.prim;
-            h.inst = r.inst;
-            h.beta = r.beta;
-            h.gamma = r.gamma;
-            out[i] = h;
-            if (COUNT) {
-                counts[2 * i] = nb;
-                counts[2 * i + 1] = nt;
-            }
-        },
-        sv.stealMinIdle, sv.stealLeafPct
-#ifdef RT_DEV_STATS
-        , COUNT ? counts + 2 * (size_t)q.nRays : nullptr
-#endif
-    );
-}
-
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void trace_any_queue_kernel(SceneView sv, RayQueue q, uint64_t nb8, const float* __restrict__ ro,
-                                                             const float* __restrict__ rd, const float* __restrict__ tmaxIn,
-                                                             uint8_t* __restrict__ occ)
-{
-    __shared__ QueueLds<false> lds;
-    const int lane = threadIdx.x;
-    trace_wave_queue<true, false>(
-        sv, q, lds, lane,
-        [&](uint32_t p, F3& o, F3& d, float& tmax) {
-            const size_t i = interleave8(p, nb8);
-            o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
-            d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-            tmax = tmaxIn[i];
-        },
-        [&](uint32_t p, const TraceResult& r, uint32_t, uint32_t) { occ[interleave8(p, nb8)] = r.inst != kInvalid ? 1 : 0; },
-        sv.stealMinIdle, sv.stealLeafPct);
-}
-
 __global__ __launch_bounds__(64) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
                                                              const float* __restrict__ rd, const float* __restrict__ tmax,
                                                              uint64_t n, uint64_t nb8, uint8_t* __restrict__ occ)
 {
-    __shared__ StealLds lds;
+    __shared__ StealLds<false> lds;
     const int lane = threadIdx.x;
     const uint64_t i = interleave8((uint64_t)blockIdx.x * 64 + lane, nb8);
     const bool has = i < n;
@@ -197,39 +148,6 @@ static int env_int(const char* name, int def)
     return e ? atoi(e) : def;
 }
 
-// Number of waves of `kernel` (64 threads, static LDS only) the current device keeps resident.
-template <class K>
-static int resident_waves(K kernel)
-{
-    int dev = 0, cus = 0, perCu = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return 0;
-    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&perCu, kernel, 64, 0) != hipSuccess) return 0;
-    return cus * perCu;
-}
-
-// Describes the ray queue of a persistent launch of `waves` resident waves over n rays and clears
-// its counters on the stream.  The grid size is returned in `grid`.
-hipError_t make_ray_queue(const SceneView& sv, uint64_t n, int resident, hipStream_t stream, RayQueue& q, unsigned& grid)
-{
-    static std::atomic<uint32_t> ring{0};
-    const uint64_t chunks = (n + 63) / 64;
-    uint64_t g = std::min<uint64_t>(chunks, (uint64_t)std::max(resident, 8));
-    if (const char* e = getenv("RTGPU_QUEUE_WAVES")) g = std::min<uint64_t>(chunks, (uint64_t)std::max(1, atoi(e)));
-    if (g >= 8) g &= ~7ull;   // whole multiples of the 8 XCDs
-    grid = (unsigned)g;
-    q.nRays = (uint32_t)n;
-    q.firstQueued = (uint32_t)std::min<uint64_t>(g * 64, n);
-    q.nCounters = kQueueCounters;
-    const uint64_t rest = n - q.firstQueued;
-    q.rangeSize = (uint32_t)(((rest + q.nCounters - 1) / q.nCounters + 63) / 64 * 64);
-    if (q.rangeSize == 0) q.rangeSize = 64;
-    q.fetchMin = sv.queueFetchMin;
-    q.xcdStride = (g >= 8) ? (uint32_t)(g / 8) : 0u;
-    q.counters = sv.queueCounters + (size_t)(ring.fetch_add(1) % kQueueRing) * kQueueCounters * 64;
-    return hipMemsetAsync(q.counters, 0, (size_t)kQueueCounters * 64 * sizeof(uint32_t), stream);
-}
-
 hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const float* dD, uint64_t n,
                                 rtgpu_hit* dHits, uint32_t* dCounts, hipStream_t stream)
 {
@@ -253,20 +171,10 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
-    if (sv.singleMesh && variant == 0 && n < 0xFFFFFF00ull) {
-        static const int resA = resident_waves(trace_closest_queue_kernel<false>), resB = resident_waves(trace_closest_queue_kernel<true>);
-        RayQueue q;
-        unsigned g = 0;
-        const hipError_t e = make_ray_queue(sv, n, dCounts ? resB : resA, stream, q, g);
-        if (e != hipSuccess) return e;
-        if (dCounts) hipLaunchKernelGGL((trace_closest_queue_kernel<true>), dim3(g), block, 0, stream, sv, q, interleave_blocks(n), dO, dD, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_queue_kernel<false>), dim3(g), block, 0, stream, sv, q, interleave_blocks(n), dO, dD, dHits, dCounts);
-        return hipGetLastError();
-    }
     if (sv.singleMesh && variant != -1) {
         const uint64_t nb8 = interleave_blocks(n);
         if (dCounts) hipLaunchKernelGGL((trace_closest_steal_kernel<true>), grid, block, 0, stream, sv, dO, dD, n, nb8, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, 0, stream, sv, dO, dD, n, nb8, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, (size_t)env_int("RTGPU_TRACE_EXTRA_LDS", 0), stream, sv, dO, dD, n, nb8, dHits, dCounts);
         return hipGetLastError();
     }
     if (sv.singleMesh) {
@@ -287,14 +195,7 @@ hipError_t launch_trace_any(const SceneView& sv, const float* dO, const float* d
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
     static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
-    if (sv.singleMesh && variant == 0 && n < 0xFFFFFF00ull) {
-        static const int res = resident_waves(trace_any_queue_kernel);
-        RayQueue q;
-        unsigned g = 0;
-        const hipError_t e = make_ray_queue(sv, n, res, stream, q, g);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(trace_any_queue_kernel, dim3(g), block, 0, stream, sv, q, interleave_blocks(n), dO, dD, dTmax, dOcc);
-    } else if (sv.singleMesh && variant != -1) hipLaunchKernelGGL(trace_any_steal_kernel, grid, block, 0, stream, sv, dO, dD, dTmax, n, interleave_blocks(n), dOcc);
+    if (sv.singleMesh && variant != -1) hipLaunchKernelGGL(trace_any_steal_kernel, grid, block, 0, stream, sv, dO, dD, dTmax, n, interleave_blocks(n), dOcc);
     else if (sv.singleMesh) hipLaunchKernelGGL((trace_any_kernel<false>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     else hipLaunchKernelGGL((trace_any_kernel<true>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     return hipGetLastError();
