@@ -5,10 +5,10 @@
 //
 //   primary : one lane per (pixel, geometry sample i): camera ray + closest hit + the area-light
 //             pre-test and the miss/environment case (Renderer.cpp:150-225)
-//   init    : one lane per path (pixel, i, material sample j): path state from the sample's hit
 //   shade   : one lane per live path vertex: material closure (Diffuse / Glossy / Emissive /
 //             ConstMix), next-event estimation, Russian roulette; emits one extension ray or one
-//             shadow ray, or ends the path
+//             shadow ray, or ends the path.  The first shade pass of a batch runs one lane per
+//             path (pixel, i, material sample j) and takes vertex 0 from the sample's primary hit
 //   shadow  : any-hit query; an unoccluded path receives its pending contribution
 //   extend  : closest-hit query for the extension rays
 //   resolve : per pixel, sums the path values in the reference's order and writes the frame buffer
@@ -48,35 +48,36 @@ constexpr uint32_t ST_GLOSSY_PENDING = 1u << 7;
 constexpr uint32_t ST_GLOSSY_ROUGH = 1u << 8;
 constexpr uint32_t ST_RETRACE = 1u << 9;
 
+// Path state lives in 16-byte records so that every access is one full-width load or store per
+// lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
+// arrays would each cost a memory transaction of their own).
 struct Pool {
-    float* ro;            // 3 per path: origin of the ray that produced the current hit / of the pending ray
-    float* rd;            // 3 per path
-    float* hitT;
-    uint32_t* hitSlot;
-    uint32_t* hitInst;
-    float* hitBeta;
-    float* hitGamma;
-    float* thr;           // 3 per path: throughput
-    float* contrib;       // 3 per path: pending contribution (shadow ray) or the glossy vertex's hit point
-    float* tmax;          // shadow-ray limit
-    uint32_t* state;
-    float* result;        // 3 per path
-    // per sample (pixel, i)
-    float* sRo;
-    float* sRd;
-    float* sT;
-    uint32_t* sSlot;
-    uint32_t* sInst;
-    float* sBeta;
-    float* sGamma;
+    float4* rayA;         // per path: origin of the pending ray / of the ray that produced the current hit; w = shadow-ray limit
+    float4* rayB;         // per path: direction; w = state bits
+    float4* hit;          // per path: t, leaf slot (bits), beta, gamma of the current vertex
+    uint32_t* hitInst;    // per path: instance of the current vertex (scenes that are not a single mesh)
+    float4* thr;          // per path: throughput
+    float4* aux;          // per path: pending contribution (shadow ray) or the glossy vertex's hit point
+    float4* result;       // per path
+    // per sample (pixel, i): the primary ray and its hit
+    float4* sA;           // origin, t
+    float4* sB;           // direction
+    float4* sC;           // leaf slot (bits), instance (bits), beta, gamma
     uint8_t* sLive;       // 1: paths are spawned from this sample
     uint8_t* sHasVar;     // 1: the sample's path reached a vertex with variance (divide by materialAA)
     // queues
     uint32_t* qA;
     uint32_t* qB;
     uint32_t* qShadow;
-    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] init queue size, [3] prefix rays repeated per material sample
+    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] unused, [3] prefix rays repeated per material sample
 };
+
+__device__ __forceinline__ float4 f4(float x, float y, float z, float w)
+{
+    float4 r;
+    r.x = x; r.y = y; r.z = z; r.w = w;
+    return r;
+}
 
 struct Batch {
     uint32_t pixelStart;  // first tile-local pixel index of the batch
@@ -168,7 +169,6 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     if (!has) return;
     const bool hit = r.inst != kInvalid;
 
-    float* res0 = pool.result + (size_t)s * M * 3;
     RGBf value = rgb(0, 0, 0);
     bool live = hit;
     // an area light closer than the hit (renderer/Renderer.cpp:184-204)
@@ -190,36 +190,12 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     pool.sLive[s] = live ? 1 : 0;
     pool.sHasVar[s] = 0;
     if (!live) {
-        res0[0] = value.r; res0[1] = value.g; res0[2] = value.b;
+        pool.result[(size_t)s * M] = f4(value.r, value.g, value.b, 0.0f);
         return;
     }
-    pool.sRo[3 * s] = o.x; pool.sRo[3 * s + 1] = o.y; pool.sRo[3 * s + 2] = o.z;
-    pool.sRd[3 * s] = d.x; pool.sRd[3 * s + 1] = d.y; pool.sRd[3 * s + 2] = d.z;
-    pool.sT[s] = r.t; pool.sSlot[s] = r.slot; pool.sInst[s] = r.inst; pool.sBeta[s] = r.beta; pool.sGamma[s] = r.gamma;
-}
-
-// ---- init ------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void init_kernel(Pool pool, uint32_t nPaths, uint32_t M, uint32_t* counter)
-{
-    const uint32_t p = blockIdx.x * 256u + threadIdx.x;
-    const bool inRange = p < nPaths;
-    bool live = false;
-    if (inRange) {
-        const uint32_t s = p / M, j = p % M;
-        live = pool.sLive[s] != 0;
-        if (live || j != 0) { pool.result[3 * (size_t)p] = 0.0f; pool.result[3 * (size_t)p + 1] = 0.0f; pool.result[3 * (size_t)p + 2] = 0.0f; }
-        if (live) {
-            for (int c = 0; c < 3; ++c) {
-                pool.ro[3 * (size_t)p + c] = pool.sRo[3 * (size_t)s + c];
-                pool.rd[3 * (size_t)p + c] = pool.sRd[3 * (size_t)s + c];
-                pool.thr[3 * (size_t)p + c] = 1.0f;
-            }
-            pool.hitT[p] = pool.sT[s]; pool.hitSlot[p] = pool.sSlot[s]; pool.hitInst[p] = pool.sInst[s];
-            pool.hitBeta[p] = pool.sBeta[s]; pool.hitGamma[p] = pool.sGamma[s];
-            pool.state[p] = 0u;
-        }
-    }
-    queue_push(pool.qA, counter, live, p);
+    pool.sA[s] = f4(o.x, o.y, o.z, r.t);
+    pool.sB[s] = f4(d.x, d.y, d.z, 0.0f);
+    pool.sC[s] = f4(__uint_as_float(r.slot), __uint_as_float(r.inst), r.beta, r.gamma);
 }
 
 // World-space shading normal of a hit: interpolated vertex normals (shape/TriangleMesh.cpp:114-120)
@@ -246,28 +222,51 @@ __device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance&
 }
 
 // ---- shade -----------------------------------------------------------------------------------
+// FIRST: the batch's first pass -- lane q is path q, vertex 0 is its sample's primary hit, and
+// nothing has been written for the path yet.  Otherwise lane q shades path qIn[q].
+// A path's result is stored when the path ends here (black unless it collected something); a path
+// that goes on through a shadow ray gets black here and its contribution from the shadow stage.
+template <bool FIRST>
 __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
                                                     const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
 {
     const uint32_t q = blockIdx.x * 256u + threadIdx.x;
     bool pushExt = false, pushShadow = false, repeated = false;
     uint32_t p = 0;
-    if (q < nIn) {
-        p = qIn[q];
-        const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    bool active = q < nIn;
+    if (FIRST && active) active = pool.sLive[q / M] != 0;
+    if (active) {
+        p = FIRST ? q : qIn[q];
         const int maxLen = st.max_path_length;
         const uint32_t s = p / M, j = p % M;
         const uint32_t pl = s / G, i = s % G;
         int px, py;
         const uint32_t pixel = tile_pixel(st, batch.pixelStart + pl, px, py);
-        uint32_t state = pool.state[p];
+        const float4 ra = FIRST ? pool.sA[s] : pool.rayA[p];
+        const float4 rb = FIRST ? pool.sB[s] : pool.rayB[p];
+        float4 hc;
+        uint32_t inst;
+        if (FIRST) {
+            const float4 c = pool.sC[s];
+            hc = f4(ra.w, c.x, c.z, c.w);
+            inst = __float_as_uint(c.y);
+        } else {
+            hc = pool.hit[p];
+            inst = sv.singleMesh ? (__float_as_uint(hc.y) != kInvalid ? 0u : kInvalid) : pool.hitInst[p];
+        }
+        uint32_t state = FIRST ? 0u : __float_as_uint(rb.w);
         int k = (int)(state & ST_K_MASK);
-        F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
-        F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
-        RGBf thr = rgb(pool.thr[3 * (size_t)p], pool.thr[3 * (size_t)p + 1], pool.thr[3 * (size_t)p + 2]);
-        const float t = pool.hitT[p];
-        const uint32_t inst = pool.hitInst[p];
+        F3 o = f3(ra.x, ra.y, ra.z);
+        F3 d = f3(rb.x, rb.y, rb.z);
+        RGBf thr = rgb(1.0f, 1.0f, 1.0f);
+        if (!FIRST) { const float4 tq = pool.thr[p]; thr = rgb(tq.x, tq.y, tq.z); }
+        const float t = hc.x;
         const bool hit = inst != kInvalid;
+        // what the path leaves behind for the next stage
+        float outTmax = 0.0f;
+        F3 outAux = f3(0, 0, 0);
+        bool writeThr = false, writeAux = false;
         bool passed = (state & ST_PASSED_VAR) != 0;
         bool done = false;
         RGBf result = rgb(0, 0, 0);
@@ -307,11 +306,11 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
                     state &= ~(ST_GLOSSY_PENDING | ST_GLOSSY_ROUGH);
                     if (!hit) {
                         // ctx.nextHit is empty: samplePath traces again from hitpoint + dir * 1e-4 (Renderer.cpp:57-61)
-                        const F3 hp = f3(pool.contrib[3 * (size_t)p], pool.contrib[3 * (size_t)p + 1], pool.contrib[3 * (size_t)p + 2]);
+                        const float4 hq = pool.aux[p];
+                        const F3 hp = f3(hq.x, hq.y, hq.z);
                         o = hp + (d * 0.0001f);
-                        pool.ro[3 * (size_t)p] = o.x; pool.ro[3 * (size_t)p + 1] = o.y; pool.ro[3 * (size_t)p + 2] = o.z;
-                        pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
-                        pool.state[p] = state | ST_RETRACE;
+                        state |= ST_RETRACE;
+                        writeThr = true;
                         pushExt = true;
                         done = true; // nothing more for this vertex now
                     } else {
@@ -339,8 +338,8 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
         if (!done) {
             // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
             const DevInstance& in = sv.inst[inst];
-            const uint32_t slot = pool.hitSlot[p];
-            const float beta = pool.hitBeta[p], gamma = pool.hitGamma[p];
+            const uint32_t slot = __float_as_uint(hc.y);
+            const float beta = hc.z, gamma = hc.w;
             uint32_t mi = in.material;
             if (slot != kInvalid && sv.triMaterial) {
                 const uint32_t tm = sv.triMaterial[slot];
@@ -385,11 +384,11 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
                             const RGBf direct = rgb_scale_d(ns.radiance, angle);
                             const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensity / RT_PI), 2.0f);
                             const RGBf c = rgb_mul(thr, rgb_mul(color, value));
-                            const F3 so = hitpoint + (ns.dir * 0.0001f);
-                            pool.ro[3 * (size_t)p] = so.x; pool.ro[3 * (size_t)p + 1] = so.y; pool.ro[3 * (size_t)p + 2] = so.z;
-                            pool.rd[3 * (size_t)p] = ns.dir.x; pool.rd[3 * (size_t)p + 1] = ns.dir.y; pool.rd[3 * (size_t)p + 2] = ns.dir.z;
-                            pool.tmax[p] = ns.tmax;
-                            pool.contrib[3 * (size_t)p] = c.r; pool.contrib[3 * (size_t)p + 1] = c.g; pool.contrib[3 * (size_t)p + 2] = c.b;
+                            o = hitpoint + (ns.dir * 0.0001f);
+                            d = ns.dir;
+                            outTmax = ns.tmax;
+                            outAux = f3(c.r, c.g, c.b);
+                            writeAux = true;
                             pushShadow = true;
                         }
                     } else {
@@ -407,12 +406,10 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
                             const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
                             const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
                             thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
-                            const F3 eo = hitpoint + (dir * 0.0001f);
-                            pool.ro[3 * (size_t)p] = eo.x; pool.ro[3 * (size_t)p + 1] = eo.y; pool.ro[3 * (size_t)p + 2] = eo.z;
-                            pool.rd[3 * (size_t)p] = dir.x; pool.rd[3 * (size_t)p + 1] = dir.y; pool.rd[3 * (size_t)p + 2] = dir.z;
-                            pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
+                            o = hitpoint + (dir * 0.0001f);
+                            d = dir;
+                            writeThr = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
-                            pool.state[p] = state;
                             pushExt = true;
                             done = true;
                         }
@@ -430,11 +427,11 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
                             const float f = ggx_brdf(roughness, -d, ns.dir, normal, micro);
                             const RGBf neeRadiance = rgb_scale_d(rgb_scale_d(ns.radiance, angle), f);
                             const RGBf c = rgb_mul(thr, rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color));
-                            const F3 so = hitpoint + (ns.dir * 0.0001f);
-                            pool.ro[3 * (size_t)p] = so.x; pool.ro[3 * (size_t)p + 1] = so.y; pool.ro[3 * (size_t)p + 2] = so.z;
-                            pool.rd[3 * (size_t)p] = ns.dir.x; pool.rd[3 * (size_t)p + 1] = ns.dir.y; pool.rd[3 * (size_t)p + 2] = ns.dir.z;
-                            pool.tmax[p] = ns.tmax;
-                            pool.contrib[3 * (size_t)p] = c.r; pool.contrib[3 * (size_t)p + 1] = c.g; pool.contrib[3 * (size_t)p + 2] = c.b;
+                            o = hitpoint + (ns.dir * 0.0001f);
+                            d = ns.dir;
+                            outTmax = ns.tmax;
+                            outAux = f3(c.r, c.g, c.b);
+                            writeAux = true;
                             pushShadow = true;
                         }
                     } else {
@@ -447,23 +444,26 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
                         done = true;
                         if (!(dot3(sampleDir, normal) < 0)) {
                             thr = rgb_mul(thr, color);
-                            const F3 eo = hitpoint + (sampleDir * 0.001f);
-                            pool.ro[3 * (size_t)p] = eo.x; pool.ro[3 * (size_t)p + 1] = eo.y; pool.ro[3 * (size_t)p + 2] = eo.z;
-                            pool.rd[3 * (size_t)p] = sampleDir.x; pool.rd[3 * (size_t)p + 1] = sampleDir.y; pool.rd[3 * (size_t)p + 2] = sampleDir.z;
-                            pool.thr[3 * (size_t)p] = thr.r; pool.thr[3 * (size_t)p + 1] = thr.g; pool.thr[3 * (size_t)p + 2] = thr.b;
-                            pool.contrib[3 * (size_t)p] = hitpoint.x; pool.contrib[3 * (size_t)p + 1] = hitpoint.y; pool.contrib[3 * (size_t)p + 2] = hitpoint.z;
+                            o = hitpoint + (sampleDir * 0.001f);
+                            d = sampleDir;
+                            writeThr = true;
+                            outAux = hitpoint;
+                            writeAux = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
-                            pool.state[p] = state;
                             pushExt = true;
                         }
                     }
                 }
             }
         }
-        repeated = j != 0 && (pool.state[p] & ST_PASSED_VAR) == 0;
-        if (haveResult) {
-            pool.result[3 * (size_t)p] = result.r; pool.result[3 * (size_t)p + 1] = result.g; pool.result[3 * (size_t)p + 2] = result.b;
+        repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
+        if (pushExt || pushShadow) {
+            pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
+            pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
+            if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
+            if (writeAux) pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, 0.0f);
         }
+        if (!pushExt) pool.result[p] = haveResult ? f4(result.r, result.g, result.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
     }
     queue_push(qExt, pool.counters + 0, pushExt, p);
     queue_push(pool.qShadow, pool.counters + 1, pushShadow, p);
@@ -483,15 +483,9 @@ __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uin
     const uint32_t q = blockIdx.x * 64u + lane;
     const bool has = q < n;
     const uint32_t p = pool.qShadow[has ? q : 0u];
-    const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
-    const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
-    const float tmax = pool.tmax[p];
-    const bool occluded = wave_any<INSTANCED>(sv, has, o, d, tmax, lds, lane);
-    if (has && !occluded) {
-        pool.result[3 * (size_t)p] = pool.contrib[3 * (size_t)p];
-        pool.result[3 * (size_t)p + 1] = pool.contrib[3 * (size_t)p + 1];
-        pool.result[3 * (size_t)p + 2] = pool.contrib[3 * (size_t)p + 2];
-    }
+    const float4 ra = pool.rayA[p], rb = pool.rayB[p];
+    const bool occluded = wave_any<INSTANCED>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), ra.w, lds, lane);
+    if (has && !occluded) pool.result[p] = pool.aux[p];
 }
 
 // ---- extend --------------------------------------------------------------------------------------
@@ -503,11 +497,11 @@ __global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, con
     const uint32_t q = blockIdx.x * 64u + lane;
     const bool has = q < n;
     const uint32_t p = queue[has ? q : 0u];
-    const F3 o = f3(pool.ro[3 * (size_t)p], pool.ro[3 * (size_t)p + 1], pool.ro[3 * (size_t)p + 2]);
-    const F3 d = f3(pool.rd[3 * (size_t)p], pool.rd[3 * (size_t)p + 1], pool.rd[3 * (size_t)p + 2]);
-    const TraceResult r = wave_closest<INSTANCED>(sv, has, o, d, lds, lane);
+    const float4 ra = pool.rayA[p], rb = pool.rayB[p];
+    const TraceResult r = wave_closest<INSTANCED>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), lds, lane);
     if (!has) return;
-    pool.hitT[p] = r.t; pool.hitSlot[p] = r.slot; pool.hitInst[p] = r.inst; pool.hitBeta[p] = r.beta; pool.hitGamma[p] = r.gamma;
+    pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
+    if (INSTANCED) pool.hitInst[p] = r.inst;
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
@@ -524,10 +518,10 @@ __global__ __launch_bounds__(256) void resolve_kernel(Pool pool, rtgpu_render_se
     RGBf px = rgb(0, 0, 0);
     for (uint32_t i = 0; i < G; ++i) {
         const uint32_t s = pl * G + i;
-        const float* r = pool.result + (size_t)s * M * 3;
-        RGBf m = rgb(r[0], r[1], r[2]);
+        const float4* r = pool.result + (size_t)s * M;
+        RGBf m = rgb(r[0].x, r[0].y, r[0].z);
         if (pool.sLive[s] && pool.sHasVar[s]) {
-            for (uint32_t j = 1; j < M; ++j) { m.r += r[3 * j]; m.g += r[3 * j + 1]; m.b += r[3 * j + 2]; }
+            for (uint32_t j = 1; j < M; ++j) { const float4 v = r[j]; m.r += v.x; m.g += v.y; m.b += v.z; }
             m = rgb_scale_f(m, 1.0f / (float)M);
         }
         px.r += m.r; px.g += m.g; px.b += m.b;
@@ -587,7 +581,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint64_t pathsPerPixel = (uint64_t)G * M;
 
-    uint64_t capPaths = 1ull << 23; // paths resident per batch (about 100 bytes of state each)
+    uint64_t capPaths = 1ull << 23; // paths resident per batch (about 110 bytes of state each)
     if (const char* e = std::getenv("RTGPU_BATCH_PATHS")) {
         const long long v = std::atoll(e);
         if (v > 0) capPaths = (uint64_t)v;
@@ -600,13 +594,10 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
 
     Workspace ws;
     Pool pool{};
-    pool.ro = ws.alloc<float>(3 * P); pool.rd = ws.alloc<float>(3 * P);
-    pool.hitT = ws.alloc<float>(P); pool.hitSlot = ws.alloc<uint32_t>(P); pool.hitInst = ws.alloc<uint32_t>(P);
-    pool.hitBeta = ws.alloc<float>(P); pool.hitGamma = ws.alloc<float>(P);
-    pool.thr = ws.alloc<float>(3 * P); pool.contrib = ws.alloc<float>(3 * P); pool.tmax = ws.alloc<float>(P);
-    pool.state = ws.alloc<uint32_t>(P); pool.result = ws.alloc<float>(3 * P);
-    pool.sRo = ws.alloc<float>(3 * S); pool.sRd = ws.alloc<float>(3 * S); pool.sT = ws.alloc<float>(S);
-    pool.sSlot = ws.alloc<uint32_t>(S); pool.sInst = ws.alloc<uint32_t>(S); pool.sBeta = ws.alloc<float>(S); pool.sGamma = ws.alloc<float>(S);
+    pool.rayA = ws.alloc<float4>(P); pool.rayB = ws.alloc<float4>(P); pool.hit = ws.alloc<float4>(P);
+    pool.hitInst = ws.alloc<uint32_t>(sv.singleMesh ? 1 : P);
+    pool.thr = ws.alloc<float4>(P); pool.aux = ws.alloc<float4>(P); pool.result = ws.alloc<float4>(P);
+    pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
     pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
     pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
     pool.counters = ws.alloc<uint32_t>(4);
@@ -630,19 +621,16 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
             if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
             else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
-            hipLaunchKernelGGL(init_kernel, dim3((nP + 255) / 256), dim3(256), 0, stream, pool, nP, M, pool.counters + 2);
             primary += nS;
             uint32_t h[4];
-            RT_TRY(hipMemcpyAsync(h, pool.counters, sizeof(h), hipMemcpyDeviceToHost, stream));
-            RT_TRY(hipStreamSynchronize(stream));
-            uint32_t nActive = h[2];
+            uint32_t nActive = nP;   // the first shade pass runs over every path of the batch
             uint32_t* qIn = pool.qA;
             uint32_t* qOut = pool.qB;
             // at most one glossy re-trace step per vertex on top of the vertex steps
             for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
-                RT_TRY(hipMemsetAsync(pool.counters, 0, 2 * sizeof(uint32_t), stream));
-                RT_TRY(hipMemsetAsync(pool.counters + 3, 0, sizeof(uint32_t), stream));
-                hipLaunchKernelGGL(shade_kernel, dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
+                if (step > 0) RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
+                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
+                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
                 RT_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 RT_TRY(hipStreamSynchronize(stream));
                 const uint32_t nExt = h[0], nShadow = h[1];
