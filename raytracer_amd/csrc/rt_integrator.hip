@@ -38,6 +38,10 @@
 #include "rt_shade_inl.h"
 #include "rt_steal_inl.h"
 
+#ifndef RT_SHADE_BLOCK
+#define RT_SHADE_BLOCK 256
+#endif
+
 namespace rt {
 
 namespace {
@@ -92,20 +96,29 @@ __device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, 
     return (uint32_t)(y * st.width + x);
 }
 
-// Appends `value` to a queue for every lane with pred == true using one atomic per wave.
-__device__ __forceinline__ void queue_push(uint32_t* queue, uint32_t* counter, bool pred, uint32_t value)
+// Appends `value` to the extension queue (predE) and / or the shadow queue (predS) with one atomic
+// per queue and workgroup: the waves' counts are combined through LDS first.  Atomics on one
+// address are served one after the other (about 11 ns each on this chip), so one atomic per wave
+// would bound a shade pass by the number of its waves.  Every thread of the workgroup must call.
+template <int BLOCK>
+__device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool predE, uint32_t* qS, uint32_t* cS, bool predS, uint32_t value)
 {
-    const unsigned long long mask = __ballot(pred);
-    if (mask == 0ull) return;
-    const int lane = (int)(threadIdx.x & 63u);
-    const int leader = __ffsll((long long)mask) - 1;
-    uint32_t base = 0;
-    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(mask));
-    base = (uint32_t)__shfl((int)base, leader, 64);
-    if (pred) {
-        const unsigned long long below = mask & ((1ull << lane) - 1ull);
-        queue[base + (uint32_t)__popcll(below)] = value;
+    constexpr int WAVES = BLOCK / 64;
+    __shared__ uint32_t cnt[2][WAVES];
+    __shared__ uint32_t base[2];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long mE = __ballot(predE), mS = __ballot(predS);
+    if (lane == 0) { cnt[0][wave] = (uint32_t)__popcll(mE); cnt[1][wave] = (uint32_t)__popcll(mS); }
+    __syncthreads();
+    if (threadIdx.x < 2) {
+        uint32_t total = 0;
+        for (int w = 0; w < WAVES; ++w) { const uint32_t c = cnt[threadIdx.x][w]; cnt[threadIdx.x][w] = total; total += c; }
+        base[threadIdx.x] = total ? atomicAdd(threadIdx.x == 0 ? cE : cS, total) : 0u;
     }
+    __syncthreads();
+    const unsigned long long lt = (1ull << lane) - 1ull;
+    if (predE) qE[base[0] + cnt[0][wave] + (uint32_t)__popcll(mE & lt)] = value;
+    if (predS) qS[base[1] + cnt[1][wave] + (uint32_t)__popcll(mS & lt)] = value;
 }
 
 // Per-wave LDS of a traversal kernel: the work-stealing state for single-mesh scenes, the plain
@@ -226,11 +239,13 @@ __device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance&
 // nothing has been written for the path yet.  Otherwise lane q shades path qIn[q].
 // A path's result is stored when the path ends here (black unless it collected something); a path
 // that goes on through a shadow ray gets black here and its contribution from the shadow stage.
+constexpr int kShadeBlock = RT_SHADE_BLOCK;
+
 template <bool FIRST>
-__global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
+__global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
                                                     const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
 {
-    const uint32_t q = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, repeated = false;
     uint32_t p = 0;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
@@ -465,8 +480,7 @@ __global__ __launch_bounds__(256) void shade_kernel(SceneView sv, Pool pool, rtg
         }
         if (!pushExt) pool.result[p] = haveResult ? f4(result.r, result.g, result.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
     }
-    queue_push(qExt, pool.counters + 0, pushExt, p);
-    queue_push(pool.qShadow, pool.counters + 1, pushShadow, p);
+    queue_push2<kShadeBlock>(qExt, pool.counters + 0, pushExt, pool.qShadow, pool.counters + 1, pushShadow, p);
     // Extension rays of vertices before the first variance vertex are identical for every material
     // sample j (the reference traces them once per geometry sample): count the repeats so that
     // the ray statistics only contain distinct rays.
@@ -629,8 +643,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             // at most one glossy re-trace step per vertex on top of the vertex steps
             for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
                 if (step > 0) RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
-                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
-                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + 255) / 256), dim3(256), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
+                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
+                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
                 RT_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
                 RT_TRY(hipStreamSynchronize(stream));
                 const uint32_t nExt = h[0], nShadow = h[1];

@@ -11,6 +11,6 @@ f = glob.glob(sys.argv[1] + "/*/*_kernel_stats.csv")[0]
 rows = [r for r in csv.DictReader(open(f)) if "rt::" in r["Name"]]
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
 for r in rows:
-    print("%-60s calls %5s total %9.2f ms  avg %9.1f us  %5.1f%%" % (r["Name"].split("(")[0][-60:], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
+    print("%-40s calls %5s total %9.2f ms  avg %9.1f us  %5.1f%%" % (r["Name"].split("_kernel")[0].split("::")[-1], r["Calls"], float(r["TotalDurationNs"]) / 1e6, float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot))
 print("sum of kernels %.2f ms (2 renders)" % (tot / 1e6))
 PY
