@@ -238,8 +238,11 @@ typedef struct rtgpu_scene_info {
 } rtgpu_scene_info;
 int rtgpu_scene_get_info(const rtgpu_scene* scene, rtgpu_scene_info* out);
 
-/* Per-ray traversal work counters of the closest-hit kernel, for the roofline model:
- * d_counts receives 2 uint32 per ray {node records fetched, triangles tested}. */
+/* Per-ray traversal work counters, for the roofline model: d_counts receives 2 uint32 per ray
+ * {child boxes tested, triangles tested} of the ray traversed on its own, nearer child first and
+ * pruned by its own hits (the reference's counterpart is BVHDiag, shape/bvh/BVHNode.h:11-15).
+ * Also writes the hits.  The cooperative kernel behind rtgpu_trace_closest_device tests
+ * somewhat more boxes than this (subtrees taken over by idle lanes are entered early). */
 int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
                                      uint64_t n, uint32_t* d_counts, void* hip_stream);
 

@@ -171,7 +171,16 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
-    if (sv.singleMesh && variant != -1) {
+    // Work counters are those of a ray traversed on its own (near child first, pruned by its own
+    // hits): a figure of the ray and the tree.  The cooperative kernel tests more boxes than that
+    // -- stolen subtrees are entered before the owner's nearer hit is known -- and its own count
+    // (developer statistics) is only reported on request.
+#ifdef RT_DEV_STATS
+    static const bool countCooperative = env_int("RTGPU_COUNT_COOPERATIVE", 1) != 0;
+#else
+    static const bool countCooperative = env_int("RTGPU_COUNT_COOPERATIVE", 0) != 0;
+#endif
+    if (sv.singleMesh && variant != -1 && (!dCounts || countCooperative)) {
         const uint64_t nb8 = interleave_blocks(n);
         if (dCounts) hipLaunchKernelGGL((trace_closest_steal_kernel<true>), grid, block, 0, stream, sv, dO, dD, n, nb8, dHits, dCounts);
         else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, (size_t)env_int("RTGPU_TRACE_EXTRA_LDS", 0), stream, sv, dO, dD, n, nb8, dHits, dCounts);
