@@ -32,6 +32,8 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "rt_scene.h"
@@ -606,83 +608,128 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     const uint64_t S = pixelsPerBatch * G;
     if (P >= (1ull << 31)) { err = "geometry_aa * material_aa too large for one batch"; return hipErrorInvalidValue; }
 
-    Workspace ws;
-    Pool pool{};
-    pool.rayA = ws.alloc<float4>(P); pool.rayB = ws.alloc<float4>(P); pool.hit = ws.alloc<float4>(P);
-    pool.hitInst = ws.alloc<uint32_t>(sv.singleMesh ? 1 : P);
-    pool.thr = ws.alloc<float4>(P); pool.aux = ws.alloc<float4>(P); pool.result = ws.alloc<float4>(P);
-    pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
-    pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
-    pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
-    pool.counters = ws.alloc<uint32_t>(4);
-    if (ws.err != hipSuccess) { err = std::string("render workspace: ") + hipGetErrorString(ws.err); return ws.err; }
+    // Batches are independent (disjoint pixels), so `lanes` of them are in flight at once, each on
+    // its own stream with its own workspace and host thread: the host round trip that reads the
+    // queue sizes after every shade pass and the thin late-bounce launches of one batch overlap
+    // with the other batch's kernels.
+    const uint64_t nBatches = (nPixelsTotal + pixelsPerBatch - 1) / pixelsPerBatch;
+    int lanes = 2;
+    if (const char* e = std::getenv("RTGPU_RENDER_LANES")) lanes = std::max(1, std::min(8, std::atoi(e)));
+    lanes = (int)std::min<uint64_t>((uint64_t)lanes, nBatches);
 
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        uint32_t* hostCounters = nullptr;   // pinned
+        hipError_t e = hipSuccess;
+        std::string err;
+        uint64_t primary = 0, extension = 0, shadow = 0;
+    };
+    std::vector<Lane> L((size_t)lanes);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
-    hipError_t e;
-#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); goto fail; } } while (0)
+    hipError_t e = hipSuccess;
+    auto cleanup = [&]() {
+        for (Lane& l : L) {
+            if (l.stream) (void)hipStreamDestroy(l.stream);
+            if (l.done) (void)hipEventDestroy(l.done);
+            if (l.hostCounters) (void)hipHostFree(l.hostCounters);
+        }
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+    };
+#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); cleanup(); return e; } } while (0)
     RT_TRY(hipEventCreate(&ev0));
     RT_TRY(hipEventCreate(&ev1));
+    for (Lane& l : L) {
+        RT_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+        RT_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+        RT_TRY(hipHostMalloc((void**)&l.hostCounters, 4 * sizeof(uint32_t)));
+    }
     RT_TRY(hipEventRecord(ev0, stream));
-    {
-        uint64_t primary = 0, extension = 0, shadow = 0;
+    for (Lane& l : L) RT_TRY(hipStreamWaitEvent(l.stream, ev0, 0));
+#undef RT_TRY
+
+    auto run_lane = [&](int li) {
+        Lane& ln = L[(size_t)li];
+        hipError_t le = hipSetDevice(scene.device);
+#define LN_TRY(call) do { le = (call); if (le != hipSuccess) { ln.e = le; ln.err = std::string(#call) + ": " + hipGetErrorString(le); return; } } while (0)
+        if (le != hipSuccess) { ln.e = le; ln.err = "hipSetDevice failed"; return; }
+        Workspace ws;
+        Pool pool{};
+        pool.rayA = ws.alloc<float4>(P); pool.rayB = ws.alloc<float4>(P); pool.hit = ws.alloc<float4>(P);
+        pool.hitInst = ws.alloc<uint32_t>(sv.singleMesh ? 1 : P);
+        pool.thr = ws.alloc<float4>(P); pool.aux = ws.alloc<float4>(P); pool.result = ws.alloc<float4>(P);
+        pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
+        pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
+        pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
+        pool.counters = ws.alloc<uint32_t>(4);
+        if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
+        const hipStream_t ls = ln.stream;
+        uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
-        for (uint64_t start = 0; start < nPixelsTotal; start += pixelsPerBatch) {
+        for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
+            const uint64_t start = bi * pixelsPerBatch;
             Batch batch;
             batch.pixelStart = (uint32_t)start;
             batch.nPixels = (uint32_t)std::min<uint64_t>(pixelsPerBatch, nPixelsTotal - start);
             const uint32_t nS = batch.nPixels * G;
             const uint32_t nP = nS * M;
-            RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
-            if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
-            else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, stream, sv, pool, cam, st, batch);
-            primary += nS;
-            uint32_t h[4];
+            LN_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), ls));
+            if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
+            else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
+            ln.primary += nS;
             uint32_t nActive = nP;   // the first shade pass runs over every path of the batch
             uint32_t* qIn = pool.qA;
             uint32_t* qOut = pool.qB;
             // at most one glossy re-trace step per vertex on top of the vertex steps
             for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
-                if (step > 0) RT_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), stream));
-                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
-                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, stream, sv, pool, st, batch, qIn, nActive, qOut);
-                RT_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, stream));
-                RT_TRY(hipStreamSynchronize(stream));
-                const uint32_t nExt = h[0], nShadow = h[1];
+                if (step > 0) LN_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), ls));
+                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+                LN_TRY(hipStreamSynchronize(ls));
+                const uint32_t nExt = h[0], nShadow = h[1], nRepeated = h[3];
                 if (nShadow) {
-                    if (single) hipLaunchKernelGGL((shadow_kernel<false>), dim3((nShadow + 63) / 64), dim3(64), 0, stream, sv, pool, nShadow);
-                    else hipLaunchKernelGGL((shadow_kernel<true>), dim3((nShadow + 63) / 64), dim3(64), 0, stream, sv, pool, nShadow);
+                    if (single) hipLaunchKernelGGL((shadow_kernel<false>), dim3((nShadow + 63) / 64), dim3(64), 0, ls, sv, pool, nShadow);
+                    else hipLaunchKernelGGL((shadow_kernel<true>), dim3((nShadow + 63) / 64), dim3(64), 0, ls, sv, pool, nShadow);
                 }
                 if (nExt) {
-                    if (single) hipLaunchKernelGGL((extend_kernel<false>), dim3((nExt + 63) / 64), dim3(64), 0, stream, sv, pool, qOut, nExt);
-                    else hipLaunchKernelGGL((extend_kernel<true>), dim3((nExt + 63) / 64), dim3(64), 0, stream, sv, pool, qOut, nExt);
+                    if (single) hipLaunchKernelGGL((extend_kernel<false>), dim3((nExt + 63) / 64), dim3(64), 0, ls, sv, pool, qOut, nExt);
+                    else hipLaunchKernelGGL((extend_kernel<true>), dim3((nExt + 63) / 64), dim3(64), 0, ls, sv, pool, qOut, nExt);
                 }
-                extension += nExt - h[3];
-                shadow += nShadow;
+                ln.extension += nExt - nRepeated;
+                ln.shadow += nShadow;
                 std::swap(qIn, qOut);
                 nActive = nExt;
             }
-            hipLaunchKernelGGL(resolve_kernel, dim3((batch.nPixels + 255) / 256), dim3(256), 0, stream, pool, st, batch, dRgb);
-            RT_TRY(hipGetLastError());
+            hipLaunchKernelGGL(resolve_kernel, dim3((batch.nPixels + 255) / 256), dim3(256), 0, ls, pool, st, batch, dRgb);
+            LN_TRY(hipGetLastError());
         }
-        RT_TRY(hipEventRecord(ev1, stream));
-        RT_TRY(hipStreamSynchronize(stream));
-        if (stats) {
-            float ms = 0;
-            RT_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-            stats->primary_rays = primary;
-            stats->extension_rays = extension;
-            stats->shadow_rays = shadow;
-            stats->device_ms = ms;
-        }
+        LN_TRY(hipEventRecord(ln.done, ls));
+        LN_TRY(hipStreamSynchronize(ls));   // the workspace is freed when this function returns
+#undef LN_TRY
+    };
+    {
+        std::vector<std::thread> threads;
+        for (int li = 1; li < lanes; ++li) threads.emplace_back(run_lane, li);
+        run_lane(0);
+        for (std::thread& t : threads) t.join();
     }
-    (void)hipEventDestroy(ev0);
-    (void)hipEventDestroy(ev1);
-    return hipSuccess;
-fail:
-    if (ev0) (void)hipEventDestroy(ev0);
-    if (ev1) (void)hipEventDestroy(ev1);
-    return e;
+    for (Lane& l : L)
+        if (l.e != hipSuccess) { e = l.e; err = l.err; cleanup(); return e; }
+#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); cleanup(); return e; } } while (0)
+    for (Lane& l : L) RT_TRY(hipStreamWaitEvent(stream, l.done, 0));
+    RT_TRY(hipEventRecord(ev1, stream));
+    RT_TRY(hipStreamSynchronize(stream));
+    if (stats) {
+        float ms = 0;
+        RT_TRY(hipEventElapsedTime(&ms, ev0, ev1));
+        for (Lane& l : L) { stats->primary_rays += l.primary; stats->extension_rays += l.extension; stats->shadow_rays += l.shadow; }
+        stats->device_ms = ms;
+    }
 #undef RT_TRY
+    cleanup();
+    return hipSuccess;
 }
 
 } // namespace rt

@@ -8,7 +8,7 @@ from raytracer_amd import scenes, abi, api
 ap = argparse.ArgumentParser()
 ap.add_argument("--what", default="trace,render")
 ap.add_argument("--subdiv", type=int, default=8)
-ap.add_argument("--detail", type=float, default=1.0)
+ap.add_argument("--detail", type=float, default=1.78)
 ap.add_argument("--spp", type=int, default=8)
 ap.add_argument("--w", type=int, default=1920)
 ap.add_argument("--h", type=int, default=1080)
@@ -80,5 +80,5 @@ if "render" in args.what:
     for rep in range(2):
         t0 = time.time(); stats = r.render_device(g, cam, st, fb, stream); t1 = time.time()
         rays = stats.primary_rays + stats.extension_rays + stats.shadow_rays
-        print(f"  render {args.w}x{args.h} {args.spp}x{args.spp}: wall {t1-t0:.3f}s dev {stats.device_ms:.1f} ms rays p/e/s={stats.primary_rays}/{stats.extension_rays}/{stats.shadow_rays} -> {rays/stats.device_ms/1e3:.0f} Mrays/s mean={fb.mean().item():.4f}")
+        print(f"  render {args.w}x{args.h} {args.spp}x{args.spp}: wall {t1-t0:.3f}s dev {stats.device_ms:.1f} ms rays p/e/s={stats.primary_rays}/{stats.extension_rays}/{stats.shadow_rays} -> {rays/stats.device_ms/1e3:.0f} Mrays/s mean={fb[torch.isfinite(fb)].mean().item():.4f} nonfinite={int((~torch.isfinite(fb)).sum().item())}")
     g.close()
