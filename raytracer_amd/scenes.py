@@ -257,6 +257,44 @@ def blob_scene(subdiv=8, seed=7):
     return sc, cam_m, yfov
 
 
+def cluster_scene(copies=38, subdiv=8, flatten=True, seed=7):
+    """Config 5: `copies` translated copies of the config-2 mesh on a jittered lattice (38 copies of
+    1 310 720 triangles = 49.8 M), either flattened into one triangle soup (what --soupify makes of
+    it; triangle index = copy * n_triangles + index in the mesh) or kept as instances of one mesh.
+    Translations are multiples of 1/4, so the flattened vertices are exact in float for this size.
+    Returns (scene, camera matrix, yfov); the camera sits inside the cluster."""
+    mesh = displaced_icosphere(subdiv, seed)
+    rng = np.random.RandomState(seed + 1)
+    side = int(math.ceil(copies ** (1.0 / 3.0)))
+    cells = [(i, j, k) for i in range(side) for j in range(side) for k in range(side)]
+    rng.shuffle(cells)
+    cells = cells[:copies]
+    pitch = 3.0
+    offs = np.array([[c[0] * pitch + rng.randint(-2, 3) * 0.25, c[1] * pitch + rng.randint(-2, 3) * 0.25,
+                      c[2] * pitch + rng.randint(-2, 3) * 0.25] for c in cells], dtype=np.float64)
+    sc = SceneData()
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.7, 0.7, 0.7))]
+    sc.point_lights = [((-3.0, 12.0, -3.0), (1.0, 1.0, 1.0), 3000.0)]
+    if flatten:
+        nv, nt = mesh.vertices.shape[0], mesh.indices.shape[0]
+        v = np.empty((copies * nv, 3), dtype=np.float32)
+        n = np.empty((copies * nv, 3), dtype=np.float32)
+        idx = np.empty((copies * nt, 3), dtype=np.uint32)
+        for c in range(copies):
+            v[c * nv:(c + 1) * nv] = (mesh.vertices.astype(np.float64) + offs[c][None, :]).astype(np.float32)
+            n[c * nv:(c + 1) * nv] = mesh.normals
+            idx[c * nt:(c + 1) * nt] = mesh.indices + np.uint32(c * nv)
+        sc.meshes = [MeshData(v, n, idx)]
+        sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    else:
+        mesh.tri_material = None
+        sc.meshes = [mesh]
+        sc.instances = [InstanceData(0, 0, translate(*offs[c]), translate(*(-offs[c]))) for c in range(copies)]
+    centre = (side - 1) * pitch / 2.0
+    cam_m = look_at((centre + 0.4, centre + 1.5, centre + 0.2), (centre + pitch, centre - 0.5, centre + pitch * 0.8))
+    return sc, cam_m, 0.9
+
+
 C3_DETAIL = 1.78
 
 
