@@ -271,9 +271,14 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
                 cur = ca;
             } else if (hb) {
                 cur = cb;
-            } else if (!pop()) {
-                alive = false;
-                break;
+            } else {
+#ifdef RT_DEV_STATS
+                if (COUNT) nTris += 1u << 16;   // developer build: node steps that entered neither child
+#endif
+                if (!pop()) {
+                    alive = false;
+                    break;
+                }
             }
         }
         if (!alive) break;
