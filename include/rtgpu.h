@@ -72,17 +72,20 @@ typedef enum rtgpu_material_type {
     RTGPU_MAT_DIFFUSE = 0,  /* material/DiffuseMaterial.cpp */
     RTGPU_MAT_GLOSSY = 1,   /* material/GlossyMaterial.cpp  ("specular") */
     RTGPU_MAT_EMISSIVE = 2, /* material/EmissiveMaterial.cpp */
-    RTGPU_MAT_CONSTMIX = 3  /* material/MixMaterial.h:19-26 */
+    RTGPU_MAT_CONSTMIX = 3, /* material/MixMaterial.h:19-26 */
+    RTGPU_MAT_FRESNELMIX = 4,  /* material/FresnelMixMaterial.cpp:3-41: mix whose factor is the Fresnel reflectance
+                                * of the hit (clear coat); `roughness` carries the index of refraction */
+    RTGPU_MAT_TRANSPARENT = 5  /* material/TransparentMaterial.cpp:3-26: the path goes straight on */
 } rtgpu_material_type;
 
 typedef struct rtgpu_material {
     int32_t type;       /* rtgpu_material_type */
     float color[3];     /* diffuseColor / color */
     double intensity;   /* diffuseIntensity / emissive intensity */
-    float roughness;    /* glossy */
+    float roughness;    /* glossy: roughness; fresnel mix: IOR (FresnelMixMaterial.h: float IOR = 1.45f) */
     float reserved;
     double mix_factor;  /* const mix: 0 = 100 % first, 1 = 100 % second */
-    uint32_t first;     /* const mix children (material ids) */
+    uint32_t first;     /* const / fresnel mix children (material ids) */
     uint32_t second;
 } rtgpu_material;
 

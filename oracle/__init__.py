@@ -45,6 +45,8 @@ def lib():
                                  C.POINTER(abi.RenderStats), C.c_int]
         L.orc_triangle_area.restype = C.c_float
         L.orc_triangle_area.argtypes = [fp, fp, fp]
+        L.orc_fresnel_mix_factor.restype = C.c_float
+        L.orc_fresnel_mix_factor.argtypes = [fp, fp, C.c_float]
         L.orc_aabb_of_transformed.argtypes = [fp, fp, C.POINTER(C.c_double), fp, fp]
         L.orc_aabb_merge.argtypes = [fp, fp, fp, fp, fp, fp]
         L.orc_aabb_area.restype = C.c_double

@@ -984,18 +984,50 @@ uint32_t hit_material(const orc_scene& S, const SceneHit& h) // Model material /
     return in.material;
 }
 
+// FresnelMixMaterial::calcMixFactor, material/FresnelMixMaterial.cpp:3-41
+float fresnel_mix_factor(V3 normal, V3 incomingDir, float IOR)
+{
+    V3 objToIncoming = -incomingDir;
+    double nDotWo = dot(normal, objToIncoming);
+    double incomingAngle = nDotWo;
+    bool isInternalRay = nDotWo < 0;
+    double curRelIor = IOR / 1.0;
+    if (isInternalRay) curRelIor = 1.0 / curRelIor;
+    double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+    bool tir = cosTransmissionSqr < 0;
+    if (tir) return 1.0;
+    if (isInternalRay) nDotWo = -nDotWo;
+    double cosRefractAngle = std::sqrt(cosTransmissionSqr);
+    double rs = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+    double rp = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+    double kr = ((rs * rs) + (rp * rp)) / 2.0;
+    double reflectionWeight = kr;
+    double transmissionWeight = 1.0 - kr;
+    double totalWeight = reflectionWeight + transmissionWeight;
+    return (float)(reflectionWeight / totalWeight);
+}
+
+// MixMaterial::calcMixFactor at a hit: ConstMixMaterial (material/MixMaterial.h:19-26) or FresnelMixMaterial
+float mat_mix_factor(const rtgpu_material& m, const SceneHit& h)
+{
+    return m.type == RTGPU_MAT_CONSTMIX ? (float)m.mix_factor : fresnel_mix_factor(h.normal, h.rd, m.roughness);
+}
+
 // IMaterial::hasVariance: Diffuse (DiffuseMaterial.cpp:228-247, no photon map) true; Glossy
-// (GlossyMaterial.cpp:226-229) roughness > 0; Emissive false; Mix (MixMaterial.cpp:59-65)
-bool mat_has_variance(const orc_scene& S, uint32_t mi)
+// (GlossyMaterial.cpp:226-229) roughness > 0; Emissive false; Transparent
+// (TransparentMaterial.cpp:23-26) false; Mix (MixMaterial.cpp:59-65)
+bool mat_has_variance(const orc_scene& S, uint32_t mi, const SceneHit& h)
 {
     const rtgpu_material& m = S.materials[mi];
     switch (m.type) {
     case RTGPU_MAT_DIFFUSE: return true;
     case RTGPU_MAT_GLOSSY: return m.roughness > 0.0f;
     case RTGPU_MAT_EMISSIVE: return false;
-    case RTGPU_MAT_CONSTMIX: {
-        float mf = (float)m.mix_factor;
-        bool noVar = (mf == 0.0f && !mat_has_variance(S, m.first)) || (mf == 1.0f && !mat_has_variance(S, m.second));
+    case RTGPU_MAT_TRANSPARENT: return false;
+    case RTGPU_MAT_CONSTMIX:
+    case RTGPU_MAT_FRESNELMIX: {
+        float mf = mat_mix_factor(m, h);
+        bool noVar = (mf == 0.0f && !mat_has_variance(S, m.first, h)) || (mf == 1.0f && !mat_has_variance(S, m.second, h));
         return !noVar;
     }
     }
@@ -1020,11 +1052,18 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     const orc_scene& S = R.S;
     const rtgpu_material& m = S.materials[mi];
     switch (m.type) {
-    case RTGPU_MAT_CONSTMIX: { // MixMaterial::sampleTransport, material/MixMaterial.cpp:9-26
-        bool choseFirst = rc.unit(DIM_MIX0 + mixLevel) > (float)m.mix_factor;
+    case RTGPU_MAT_CONSTMIX:
+    case RTGPU_MAT_FRESNELMIX: { // MixMaterial::sampleTransport, material/MixMaterial.cpp:9-26
+        bool choseFirst = rc.unit(DIM_MIX0 + mixLevel) > mat_mix_factor(m, tn.hit);
         sample_transport(R, tn, choseFirst ? m.first : m.second, sampleI, sampleCount, rc, mixLevel + 1, out);
         return;
     }
+    case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::sampleTransport, material/TransparentMaterial.cpp:3-11
+        tn.leafMat = mi;
+        tn.isEmissive = false;
+        tn.pathTerminationChance = 0.01;
+        tn.transportDirection = tn.hit.rd;
+        return;
     case RTGPU_MAT_EMISSIVE: // EmissiveMaterial::sampleTransport, material/EmissiveMaterial.cpp:5-10
         tn.leafMat = mi;
         tn.pathTerminationChance = 1.0f;
@@ -1157,6 +1196,8 @@ RGBf mat_bsdf(const orc_scene& S, const TransportNode& tn, RGBf incoming)
     }
     case RTGPU_MAT_EMISSIVE: // EmissiveMaterial::bsdf, material/EmissiveMaterial.cpp:12-22
         return rgb_scale_d(color, m.intensity);
+    case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::bsdf, material/TransparentMaterial.cpp:13-16
+        return incoming;
     default: return RGBf{};
     }
 }
@@ -1177,7 +1218,7 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
     do {
         TransportNode& cur = path[curI];
         uint32_t mi = hit_material(S, cur.hit);
-        bool curVar = mat_has_variance(S, mi);
+        bool curVar = mat_has_variance(S, mi, cur.hit);
         bool isFirstVar = curVar && !hasPassedVariance;
         int sampleCount = isFirstVar ? materialAA : 1;
         int sampleI = isFirstVar ? sampleJ : 0;
@@ -1286,7 +1327,7 @@ RGBf render_pixel(RenderCtx& R, const rtgpu_camera& cam, const rtgpu_render_sett
         bool terminated = sample_path(R, path, 0, st.max_path_length, M, 0, key);
         int firstVar = 0;
         for (; firstVar < (int)path.size(); ++firstVar)
-            if (mat_has_variance(S, hit_material(S, path[firstVar].hit))) break;
+            if (mat_has_variance(S, hit_material(S, path[firstVar].hit), path[firstVar].hit)) break;
         RGBf matSample;
         if (!terminated) matSample = path_energy(S, path);
         if (firstVar < (int)path.size()) {
@@ -1503,6 +1544,7 @@ void orc_render(const orc_scene* s, const rtgpu_camera* cam, const rtgpu_render_
 }
 
 float orc_triangle_area(const float a[3], const float b[3], const float c[3]) { return tri_area(mk(a), mk(b), mk(c)); }
+float orc_fresnel_mix_factor(const float normal[3], const float dir[3], float ior) { return fresnel_mix_factor(mk(normal), mk(dir), ior); }
 
 void orc_aabb_of_transformed(const float lo[3], const float hi[3], const double m[16], float out_lo[3], float out_hi[3])
 {

@@ -58,6 +58,8 @@ void orc_render(const orc_scene* s, const rtgpu_camera* cam, const rtgpu_render_
 
 /* Known-answer helpers (reference unit tests). */
 float orc_triangle_area(const float a[3], const float b[3], const float c[3]);
+/* FresnelMixMaterial::calcMixFactor, material/FresnelMixMaterial.cpp:3-41 */
+float orc_fresnel_mix_factor(const float normal[3], const float dir[3], float ior);
 void orc_aabb_of_transformed(const float lo[3], const float hi[3], const double m[16], float out_lo[3], float out_hi[3]);
 void orc_aabb_merge(const float lo0[3], const float hi0[3], const float lo1[3], const float hi1[3], float out_lo[3], float out_hi[3]);
 double orc_aabb_area(const float lo[3], const float hi[3]);

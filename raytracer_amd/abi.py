@@ -14,7 +14,7 @@ import numpy as np
 INVALID_ID = 0xFFFFFFFF
 SHAPE_SPHERE = -1
 
-MAT_DIFFUSE, MAT_GLOSSY, MAT_EMISSIVE, MAT_CONSTMIX = 0, 1, 2, 3
+MAT_DIFFUSE, MAT_GLOSSY, MAT_EMISSIVE, MAT_CONSTMIX, MAT_FRESNELMIX, MAT_TRANSPARENT = 0, 1, 2, 3, 4, 5
 JITTER_RANDOM, JITTER_CENTER = 0, 1
 
 c_float_p = C.POINTER(C.c_float)

@@ -112,15 +112,16 @@ int validate(const rtgpu_scene_desc* d)
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rtgpu_material& m = d->materials[i];
-        if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_CONSTMIX) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
-        if (m.type == RTGPU_MAT_CONSTMIX) {
+        if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_TRANSPARENT) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
+        auto is_mix = [&](uint32_t k) { return d->materials[k].type == RTGPU_MAT_CONSTMIX || d->materials[k].type == RTGPU_MAT_FRESNELMIX; };
+        if (is_mix(i)) {
             if (m.first >= d->n_materials || m.second >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix material child out of range");
             // nested mixes are resolved at most kMaxMixDepth deep on the device
             uint32_t depth = 0, cur = i;
-            while (d->materials[cur].type == RTGPU_MAT_CONSTMIX && depth <= 4) { cur = d->materials[cur].first; ++depth; }
+            while (is_mix(cur) && depth <= 4) { cur = d->materials[cur].first; ++depth; }
             if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
             depth = 0; cur = i;
-            while (d->materials[cur].type == RTGPU_MAT_CONSTMIX && depth <= 4) { cur = d->materials[cur].second; ++depth; }
+            while (is_mix(cur) && depth <= 4) { cur = d->materials[cur].second; ++depth; }
             if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
         }
     }
@@ -431,6 +432,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nPointLights = desc->n_point_lights;
     v.nAreaLights = desc->n_area_lights;
     v.hasEnv = desc->has_environment ? 1 : 0;
+    for (uint32_t i = 0; i < desc->n_materials; ++i)
+        if (desc->materials[i].type == RTGPU_MAT_FRESNELMIX) v.hasFresnelMix = 1;
     // ColorEnvironment::getRadiance = color * intensity (RGB * double), ColorEnvironment.cpp:6-9
     for (int a = 0; a < 3; ++a) v.envRadiance[a] = (float)((double)desc->env_color[a] * desc->env_intensity);
     info.device_bytes = bytes;

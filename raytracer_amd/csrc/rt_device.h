@@ -54,6 +54,7 @@ struct SceneView {
     const DevAreaLight* areaLights;
     uint32_t nMaterials, nPointLights, nAreaLights;
     int32_t hasEnv;
+    int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
     float envRadiance[3];
 };
 

@@ -362,7 +362,10 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 const uint32_t tm = sv.triMaterial[slot];
                 if (tm != kInvalid) mi = tm;
             }
-            const bool curVar = mat_has_variance(sv, mi);
+            // the shading normal is needed up front only when a mix factor depends on the hit
+            F3 normal = f3(0.0f, 0.0f, 0.0f);
+            if (sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
+            const bool curVar = mat_has_variance(sv, mi, normal, d);
             const bool isFirstVar = curVar && !passed;
             const int sampleCount = isFirstVar ? (int)M : 1;
             const int sampleI = isFirstVar ? (int)j : 0;
@@ -372,9 +375,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             const uint32_t rs = i * M + (passed ? j : 0u);
             const uint32_t vk = (uint32_t)k;
             // MixMaterial::sampleTransport (material/MixMaterial.cpp:9-26)
-            for (uint32_t level = 0; level < 4 && sv.materials[mi].type == RTGPU_MAT_CONSTMIX; ++level) {
+            for (uint32_t level = 0; level < 4 && mat_is_mix(sv.materials[mi]); ++level) {
                 const DevMaterial& mm = sv.materials[mi];
-                const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mm.mixFactor;
+                const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
                 mi = choseFirst ? mm.first : mm.second;
             }
             const DevMaterial& mat = sv.materials[mi];
@@ -388,8 +391,19 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 if (!lastVertex) { result = rgb_mul(thr, rgb_scale_d(color, mat.intensity)); haveResult = true; }
             } else if (lastVertex) {
                 done = true;
+            } else if (mat.type == RTGPU_MAT_TRANSPARENT) {
+                // TransparentMaterial (material/TransparentMaterial.cpp:3-16): straight on, bsdf = identity,
+                // Russian roulette 0.01 (renderer/Renderer.cpp:52, 104-107)
+                done = true;
+                if (!(rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.01f)) {
+                    thr = rgb_div_f(thr, 1.0f - 0.01f);
+                    o = hitpoint + (d * 0.0001f);
+                    writeThr = true;
+                    state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
+                    pushExt = true;
+                }
             } else {
-                const F3 normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
+                if (!sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
                 if (mat.type == RTGPU_MAT_DIFFUSE) {
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;

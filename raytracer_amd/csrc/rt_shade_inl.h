@@ -219,14 +219,47 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
     return out;
 }
 
+// FresnelMixMaterial::calcMixFactor, material/FresnelMixMaterial.cpp:3-41: unpolarised Fresnel
+// reflectance of the hit for index of refraction `ior` against air, 1 on total internal reflection.
+__device__ __forceinline__ float fresnel_mix_factor(F3 normal, F3 incomingDir, float ior)
+{
+    const F3 objToIncoming = -incomingDir;
+    double nDotWo = dot3(normal, objToIncoming);
+    const double incomingAngle = nDotWo;
+    const bool isInternalRay = nDotWo < 0;
+    double curRelIor = ior / 1.0;
+    if (isInternalRay) curRelIor = 1.0 / curRelIor;
+    const double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+    if (cosTransmissionSqr < 0) return 1.0f;
+    if (isInternalRay) nDotWo = -nDotWo;
+    const double cosRefractAngle = sqrt(cosTransmissionSqr);
+    const double rs = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+    const double rp = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+    const double kr = ((rs * rs) + (rp * rp)) / 2.0;
+    const double reflectionWeight = kr;
+    const double transmissionWeight = 1.0 - kr;
+    const double totalWeight = reflectionWeight + transmissionWeight;
+    return (float)(reflectionWeight / totalWeight);
+}
+
+__device__ __forceinline__ bool mat_is_mix(const DevMaterial& M) { return M.type == RTGPU_MAT_CONSTMIX || M.type == RTGPU_MAT_FRESNELMIX; }
+
+// MixMaterial::calcMixFactor of a mix node at this hit (material/MixMaterial.h:19-26, FresnelMixMaterial.cpp)
+__device__ __forceinline__ float mat_mix_factor(const DevMaterial& M, F3 normal, F3 incomingDir)
+{
+    return M.type == RTGPU_MAT_CONSTMIX ? M.mixFactor : fresnel_mix_factor(normal, incomingDir, M.roughness);
+}
+
 // IMaterial::hasVariance: Diffuse true (DiffuseMaterial.cpp:228-247 without photon map), Glossy
-// roughness > 0 (GlossyMaterial.cpp:226-229), Emissive false, Mix (MixMaterial.cpp:59-65).
-__device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi)
+// roughness > 0 (GlossyMaterial.cpp:226-229), Emissive and Transparent false, Mix
+// (MixMaterial.cpp:59-65; the factor of a Fresnel mix depends on the hit).
+__device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir)
 {
     // A mix has variance unless (factor==0 && !first.var) || (factor==1 && !second.var).  Mixes nest
     // at most 3 deep (checked at scene creation), so the recursion is expanded by hand.
     struct Eval {
         const SceneView& sv;
+        F3 n, d;
         __device__ bool leaf(uint32_t m) const
         {
             const DevMaterial& M = sv.materials[m];
@@ -237,26 +270,29 @@ __device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t m
         __device__ bool l3(uint32_t m) const
         {
             const DevMaterial& M = sv.materials[m];
-            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
-            const bool noVar = (M.mixFactor == 0.0f && !leaf(M.first)) || (M.mixFactor == 1.0f && !leaf(M.second));
+            if (!mat_is_mix(M)) return leaf(m);
+            const float f = mat_mix_factor(M, n, d);
+            const bool noVar = (f == 0.0f && !leaf(M.first)) || (f == 1.0f && !leaf(M.second));
             return !noVar;
         }
         __device__ bool l2(uint32_t m) const
         {
             const DevMaterial& M = sv.materials[m];
-            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
-            const bool noVar = (M.mixFactor == 0.0f && !l3(M.first)) || (M.mixFactor == 1.0f && !l3(M.second));
+            if (!mat_is_mix(M)) return leaf(m);
+            const float f = mat_mix_factor(M, n, d);
+            const bool noVar = (f == 0.0f && !l3(M.first)) || (f == 1.0f && !l3(M.second));
             return !noVar;
         }
         __device__ bool l1(uint32_t m) const
         {
             const DevMaterial& M = sv.materials[m];
-            if (M.type != RTGPU_MAT_CONSTMIX) return leaf(m);
-            const bool noVar = (M.mixFactor == 0.0f && !l2(M.first)) || (M.mixFactor == 1.0f && !l2(M.second));
+            if (!mat_is_mix(M)) return leaf(m);
+            const float f = mat_mix_factor(M, n, d);
+            const bool noVar = (f == 0.0f && !l2(M.first)) || (f == 1.0f && !l2(M.second));
             return !noVar;
         }
     };
-    return Eval{sv}.l1(mi);
+    return Eval{sv, normal, incomingDir}.l1(mi);
 }
 
 } // namespace rt

@@ -12,8 +12,8 @@ import math
 
 import numpy as np
 
-from .abi import (MAT_DIFFUSE, MAT_EMISSIVE, MAT_GLOSSY, SHAPE_SPHERE, InstanceData, MaterialData,
-                  MeshData, SceneData)
+from .abi import (MAT_CONSTMIX, MAT_DIFFUSE, MAT_EMISSIVE, MAT_FRESNELMIX, MAT_GLOSSY, MAT_TRANSPARENT, SHAPE_SPHERE,
+                  InstanceData, MaterialData, MeshData, SceneData)
 
 
 # ---------------------------------------------------------------------------------------
@@ -377,6 +377,38 @@ def box_scene(with_mirror=False):
     sc.point_lights = [((0.8, 3.0, 3.2), (1.0, 1.0, 1.0), 40.0)]
     cam_m = look_at((2.0, 2.0, 3.9), (2.0, 1.6, 0.0))
     return sc, cam_m, 0.9
+
+
+def coat_scene():
+    """The box of box_scene with the 'next' closures: a clear-coated sphere (Fresnel mix of a mirror
+    over red diffuse), a coated floor (Fresnel mix nested in a constant mix), an all-glossy Fresnel
+    mix (no variance where the mirror child is certain) and a transparent pane in front of the camera."""
+    sc, cam_m, yfov = box_scene()
+    base = len(sc.materials)
+    sc.materials += [
+        MaterialData(MAT_FRESNELMIX, roughness=1.45, first=2, second=4),          # base+0: coat: diffuse red under a mirror
+        MaterialData(MAT_FRESNELMIX, roughness=1.33, first=0, second=1),          # base+1: grey diffuse under rough glossy
+        MaterialData(MAT_CONSTMIX, mix_factor=0.35, first=base + 1, second=3),     # base+2: nested
+        MaterialData(MAT_TRANSPARENT),                                             # base+3
+        MaterialData(MAT_FRESNELMIX, roughness=1.6, first=4, second=4),            # base+4: mirror either way (no variance)
+    ]
+    mesh = sc.meshes[0]
+    tm = mesh.tri_material.copy()
+    n = 6
+    quad = 2 * n * n
+    tm[0:quad] = base + 2                     # floor
+    tm[5 * quad:6 * quad] = base + 4          # right wall
+    nsph = (len(tm) - 6 * quad) // 2
+    tm[6 * quad:6 * quad + nsph] = base + 0   # first sphere
+    pane_v, pane_f = grid_quad((1.0, 0.8, 3.2), (2.0, 0.0, 0.0), (0.0, 1.8, 0.0), 2, 2)
+    pane_v = np.asarray(pane_v, dtype=np.float32)
+    pane_f = np.asarray(pane_f, dtype=np.uint32)
+    nv = len(mesh.vertices)
+    sc.meshes = [MeshData(np.concatenate([mesh.vertices, pane_v]),
+                          np.concatenate([mesh.normals, vertex_normals(pane_v, pane_f)]),
+                          np.concatenate([mesh.indices, pane_f + np.uint32(nv)]),
+                          np.concatenate([tm, np.full(len(pane_f), base + 3, dtype=np.uint32)]))]
+    return sc, cam_m, yfov
 
 
 def random_rays(n, lo, hi, seed=0):

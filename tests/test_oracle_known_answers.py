@@ -168,3 +168,43 @@ def test_render_tile_equals_crop_of_full_frame():
     mask = np.ones((24, 32), bool)
     mask[4:16, 8:20] = False
     assert np.all(part[mask] == 0)
+
+
+def test_fresnel_mix_factor_closed_forms():
+    """FresnelMixMaterial::calcMixFactor (material/FresnelMixMaterial.cpp:3-41) against the Fresnel equations:
+    ((n-1)/(n+1))^2 at normal incidence from either side, 1 at grazing incidence and beyond the critical angle."""
+    L = oracle.lib()
+    f3 = lambda v: np.asarray(v, np.float32).ctypes.data_as(abi.c_float_p)
+    n = [0.0, 1.0, 0.0]
+    r0 = ((1.45 - 1.0) / (1.45 + 1.0)) ** 2
+    assert abs(L.orc_fresnel_mix_factor(f3(n), f3([0.0, -1.0, 0.0]), 1.45) - r0) < 1e-6
+    assert abs(L.orc_fresnel_mix_factor(f3(n), f3([0.0, 1.0, 0.0]), 1.45) - r0) < 1e-6           # leaving the medium head-on
+    g = L.orc_fresnel_mix_factor(f3(n), f3([np.sqrt(1 - 1e-6), -1e-3, 0.0]), 1.45)
+    assert 0.98 < g <= 1.0                                                                          # grazing
+    s = np.sin(np.radians(50.0))                                                                    # critical angle of 1.45 is 43.6 degrees
+    assert L.orc_fresnel_mix_factor(f3(n), f3([s, np.sqrt(1 - s * s), 0.0]), 1.45) == 1.0           # total internal reflection
+    # Schlick-free check at 60 degrees outside: average of the s and p reflectances
+    ci = 0.5; st = np.sqrt(1 - ci * ci) / 1.45; ct = np.sqrt(1 - st * st)
+    rs = ((ci - 1.45 * ct) / (ci + 1.45 * ct)) ** 2; rp = ((1.45 * ci - ct) / (1.45 * ci + ct)) ** 2
+    got = L.orc_fresnel_mix_factor(f3(n), f3([np.sqrt(0.75), -0.5, 0.0]), 1.45)
+    assert abs(got - 0.5 * (rs + rp)) < 1e-5
+
+
+def test_transparent_panes_pass_radiance_unchanged_in_expectation():
+    """TransparentMaterial (material/TransparentMaterial.cpp:3-16): direction unchanged, bsdf = identity,
+    Russian roulette 0.01 compensated by 1/(1-0.01): every sample is 0 or L/0.99^2 behind two panes, mean L."""
+    from raytracer_amd.abi import MAT_EMISSIVE, MAT_TRANSPARENT, InstanceData, MaterialData, MeshData, SceneData
+    quad = lambda z: np.array([[-5, -5, z], [5, -5, z], [5, 5, z], [-5, 5, z]], np.float32)
+    v = np.concatenate([quad(-3.0), quad(-1.0), quad(-2.0)])
+    idx = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 9, 10], [8, 10, 11]], np.uint32)
+    nrm = np.tile(np.array([[0, 0, 1]], np.float32), (12, 1))
+    sc = SceneData()
+    sc.meshes = [MeshData(v, nrm, idx, np.array([0, 0, 1, 1, 1, 1], np.uint32))]
+    sc.materials = [MaterialData(MAT_EMISSIVE, (0.5, 1.0, 0.25), intensity=2.0), MaterialData(MAT_TRANSPARENT)]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    cam = oracle.camera_from_transform(40.0, np.eye(4))
+    img, stats = oracle.OracleScene(sc).render(cam, abi.make_settings(16, 12, geometry_aa=16, material_aa=4, seed=5))
+    Lr = np.array([1.0, 2.0, 0.5])
+    assert np.allclose(img.mean(axis=(0, 1)), Lr, rtol=0.02)
+    assert img.max(axis=(0, 1))[1] <= 2.0 / (0.99 * 0.99) * 1.0001
+    assert stats.extension_rays >= 2 * 0.97 * stats.primary_rays and stats.shadow_rays == 0
