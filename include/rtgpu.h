@@ -103,6 +103,14 @@ typedef struct rtgpu_area_light { /* light/AreaLight.h (one world-space triangle
     double intensity;
 } rtgpu_area_light;
 
+typedef struct rtgpu_directional_light { /* light/DirectionalLight.h:9-24 (world space) */
+    float direction[3]; /* direction the light travels in, normalised (applyTransform, DirectionalLight.cpp:10-13) */
+    float angle;        /* "radius size in hemisphere": the sampled cone's half angle in radians */
+    float color[3];
+    float reserved;
+    double intensity;   /* irradiance */
+} rtgpu_directional_light;
+
 typedef struct rtgpu_scene_desc {
     const rtgpu_mesh_desc* meshes;
     const rtgpu_instance_desc* instances;
@@ -117,6 +125,9 @@ typedef struct rtgpu_scene_desc {
     int32_t has_environment; /* ColorEnvironment, material/environment/ColorEnvironment.cpp:6-9 */
     float env_color[3];
     double env_intensity;
+    const rtgpu_directional_light* directional_lights; /* may be null when n_directional_lights == 0 */
+    uint32_t n_directional_lights;
+    uint32_t reserved;
 } rtgpu_scene_desc;
 
 typedef struct rtgpu_scene rtgpu_scene;

@@ -610,6 +610,7 @@ struct orc_scene {
     std::vector<rtgpu_material> materials;
     std::vector<rtgpu_point_light> pointLights;
     std::vector<rtgpu_area_light> areaLights;
+    std::vector<rtgpu_directional_light> dirLights;
     bool hasEnv = false;
     RGBf envRadiance; // color * intensity, ColorEnvironment.cpp:6-9
 };
@@ -730,7 +731,7 @@ inline float rand_unit(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 
 enum Dim : uint32_t {
     DIM_NEE_CHOICE = 1, DIM_LIGHT_TYPE = 2, DIM_LIGHT_INDEX = 3, DIM_AREA_U = 4, DIM_AREA_V = 5,
-    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_MIX0 = 12
+    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_MIX0 = 12
 };
 constexpr uint32_t VERTEX_CAMERA = 255;
 
@@ -936,15 +937,40 @@ RGBf nee_area(RenderCtx& R, const rtgpu_area_light& light, V3 hitpoint, int samp
     }
     return RGBf{};
 }
-// NextEventEstimation::sample, material/NextEventEstimation.cpp:69-120 (point and area lights)
+// sampleUniformSteradianSphere, math/Sampler.h:76-88, with Transformation::rotateX/rotateY/append/
+// transform(Vector3) (math/Transformation.cpp:35-63, Transformation.h:66-69,83-87): the product matrix's
+// third column is (sin b, -sin a cos b, cos a cos b) in fp64, narrowed to float by transform().
+V3 sample_steradian_sphere(V3 center, float angle, float r0, float r1)
+{
+    float alpha = (r0 - 0.5f) * 2.0f * angle;
+    float beta = (r1 - 0.5f) * 2.0f * angle;
+    double sa = std::sin((double)alpha), ca = std::cos((double)alpha), sb = std::sin((double)beta), cb = std::cos((double)beta);
+    V3 l{(float)sb, (float)(-sa * cb), (float)(ca * cb)};
+    Basis basis = basis_from(center);
+    return V3{basis.u.x * l.x + (basis.v.x * l.y + basis.w.x * l.z),
+              basis.u.y * l.x + (basis.v.y * l.y + basis.w.y * l.z),
+              basis.u.z * l.x + (basis.v.z * l.y + basis.w.z * l.z)};
+}
+// neeDirectionalLight, material/NextEventEstimation.cpp:55-67
+RGBf nee_directional(RenderCtx& R, const rtgpu_directional_light& light, V3 hitpoint, const RandCtx& rc, V3& lightDirection)
+{
+    lightDirection = sample_steradian_sphere(-mk(light.direction), light.angle, rc.unit(DIM_DIR_ALPHA), rc.unit(DIM_DIR_BETA));
+    R.shadow++;
+    bool isVisible = !scene_visibility(R.S, hitpoint + (lightDirection * 0.0001f), lightDirection, INFINITY);
+    if (isVisible) return light_energy(light.color, light.intensity);
+    return RGBf{};
+}
+// NextEventEstimation::sample, material/NextEventEstimation.cpp:69-120
 RGBf nee_sample(RenderCtx& R, V3 hitpoint, int sampleI, int sampleCount, const RandCtx& rc, V3& lightDirection)
 {
     const orc_scene& S = R.S;
     bool hasPoint = !S.pointLights.empty();
     bool hasArea = !S.areaLights.empty();
-    float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f);
+    bool hasDir = !S.dirLights.empty();
+    float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f) + (hasDir ? 1.0f : 0.0f);
     float pointP = (hasPoint ? 1.0f : 0.0f) / total;
     float areaP = (hasArea ? 1.0f : 0.0f) / total;
+    float dirP = (hasDir ? 1.0f : 0.0f) / total;
     float choice = rc.unit(DIM_LIGHT_TYPE);
     if (choice < pointP) {
         size_t n = S.pointLights.size();
@@ -956,6 +982,11 @@ RGBf nee_sample(RenderCtx& R, V3 hitpoint, int sampleI, int sampleCount, const R
         float chosenP = 1.0f / n;
         size_t idx = std::min(n - 1, (size_t)(rc.unit(DIM_LIGHT_INDEX) * (float)n));
         return rgb_div_f(nee_area(R, S.areaLights[idx], hitpoint, sampleI, sampleCount, rc, lightDirection), areaP * chosenP);
+    } else if (hasDir) {
+        size_t n = S.dirLights.size();
+        float chosenP = 1.0f / n;
+        size_t idx = std::min(n - 1, (size_t)(rc.unit(DIM_LIGHT_INDEX) * (float)n));
+        return rgb_div_f(nee_directional(R, S.dirLights[idx], hitpoint, rc, lightDirection), dirP * chosenP);
     }
     return RGBf{};
 }
@@ -1413,6 +1444,7 @@ orc_scene* orc_scene_create(const rtgpu_scene_desc* desc, int n_threads)
     S->materials.assign(desc->materials, desc->materials + desc->n_materials);
     S->pointLights.assign(desc->point_lights, desc->point_lights + desc->n_point_lights);
     S->areaLights.assign(desc->area_lights, desc->area_lights + desc->n_area_lights);
+    if (desc->n_directional_lights) S->dirLights.assign(desc->directional_lights, desc->directional_lights + desc->n_directional_lights);
     S->hasEnv = desc->has_environment != 0;
     S->envRadiance = rgb_scale_d(RGBf{desc->env_color[0], desc->env_color[1], desc->env_color[2]}, desc->env_intensity);
     return S;

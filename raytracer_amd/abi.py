@@ -47,13 +47,20 @@ class AreaLight(C.Structure):
                 ("color", C.c_float * 3), ("intensity", C.c_double)]
 
 
+class DirectionalLight(C.Structure):
+    _fields_ = [("direction", C.c_float * 3), ("angle", C.c_float), ("color", C.c_float * 3), ("reserved", C.c_float),
+                ("intensity", C.c_double)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("instances", C.POINTER(InstanceDesc)),
                 ("materials", C.POINTER(Material)), ("point_lights", C.POINTER(PointLight)),
                 ("area_lights", C.POINTER(AreaLight)),
                 ("n_meshes", C.c_uint32), ("n_instances", C.c_uint32), ("n_materials", C.c_uint32),
                 ("n_point_lights", C.c_uint32), ("n_area_lights", C.c_uint32),
-                ("has_environment", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_double)]
+                ("has_environment", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_double),
+                ("directional_lights", C.POINTER(DirectionalLight)), ("n_directional_lights", C.c_uint32),
+                ("reserved", C.c_uint32)]
 
 
 class Hit(C.Structure):
@@ -129,6 +136,7 @@ class SceneData:
     materials: List[MaterialData] = field(default_factory=list)
     point_lights: List[tuple] = field(default_factory=list)   # (pos3, color3, intensity)
     area_lights: List[tuple] = field(default_factory=list)    # (a3, b3, c3, color3, intensity)
+    directional_lights: List[tuple] = field(default_factory=list)  # (direction3, angle, color3, intensity)
     env: Optional[tuple] = None                               # (color3, intensity)
 
     def n_triangles(self) -> int:
@@ -195,7 +203,14 @@ class PackedScene:
             als[i].c[:] = [float(x) for x in c]
             als[i].color[:] = [float(x) for x in col]
             als[i].intensity = float(inten)
-        self._keep += [meshes, insts, mats, pls, als]
+        n_dl = len(scene.directional_lights)
+        dls = (DirectionalLight * max(1, n_dl))()
+        for i, (direction, angle, col, inten) in enumerate(scene.directional_lights):
+            dls[i].direction[:] = [float(x) for x in direction]
+            dls[i].angle = float(angle)
+            dls[i].color[:] = [float(x) for x in col]
+            dls[i].intensity = float(inten)
+        self._keep += [meshes, insts, mats, pls, als, dls]
         d = SceneDesc()
         d.meshes = meshes
         d.instances = insts
@@ -204,6 +219,8 @@ class PackedScene:
         d.area_lights = als
         d.n_meshes, d.n_instances, d.n_materials = n_meshes, n_inst, n_mat
         d.n_point_lights, d.n_area_lights = n_pl, n_al
+        d.directional_lights = dls
+        d.n_directional_lights = n_dl
         if scene.env is not None:
             d.has_environment = 1
             d.env_color[:] = [float(x) for x in scene.env[0]]

@@ -87,7 +87,8 @@ int validate(const rtgpu_scene_desc* d)
     if (d->n_instances >= (1u << 27)) return fail(RTGPU_ERR_LIMIT, "more than 2^27 instances");
     if ((d->n_meshes && !d->meshes) || !d->instances) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null mesh/instance array");
     if (d->n_materials == 0 || !d->materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene has no materials");
-    if ((d->n_point_lights && !d->point_lights) || (d->n_area_lights && !d->area_lights))
+    if ((d->n_point_lights && !d->point_lights) || (d->n_area_lights && !d->area_lights) ||
+        (d->n_directional_lights && !d->directional_lights))
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "null light array");
     for (uint32_t m = 0; m < d->n_meshes; ++m) {
         const rtgpu_mesh_desc& md = d->meshes[m];
@@ -141,7 +142,7 @@ void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
-                          view.materials, view.pointLights, view.areaLights};
+                          view.materials, view.pointLights, view.areaLights, view.dirLights};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
     view = rt::SceneView{};
@@ -392,6 +393,19 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         d.intensity = L.intensity;
         rt::area_light_derived(d);
     }
+    std::vector<DevDirectionalLight> dls(desc->n_directional_lights);
+    for (uint32_t i = 0; i < desc->n_directional_lights; ++i) {
+        const rtgpu_directional_light& L = desc->directional_lights[i];
+        DevDirectionalLight& d = dls[i];
+        std::memcpy(d.dir, L.direction, 12);
+        d.angle = L.angle;
+        std::memcpy(d.color, L.color, 12);
+        d.pad = 0.0f;
+        d.intensity = L.intensity;
+        // OrthonormalBasis(-direction) throws on a zero vector (math/OrthonormalBasis.cpp:13-16)
+        if (L.direction[0] == 0.0f && L.direction[1] == 0.0f && L.direction[2] == 0.0f)
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "directional light with a zero direction");
+    }
 
     const auto t1 = std::chrono::steady_clock::now();
     info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
@@ -410,7 +424,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     if ((rc = upload(triIds, &v.triIds, bytes)) || (rc = upload(inst, &v.inst, bytes)) || (rc = upload(instOrder, &v.instOrder, bytes)) ||
         (rc = upload(vertNormals, &v.vertNormals, bytes)) || (rc = upload(triMat, &v.triMaterial, bytes)) ||
         (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
-        (rc = upload(als, &v.areaLights, bytes))) {
+        (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes))) {
         sc->release();
         delete sc;
         return rc;
@@ -431,6 +445,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nMaterials = desc->n_materials;
     v.nPointLights = desc->n_point_lights;
     v.nAreaLights = desc->n_area_lights;
+    v.nDirLights = desc->n_directional_lights;
     v.hasEnv = desc->has_environment ? 1 : 0;
     for (uint32_t i = 0; i < desc->n_materials; ++i)
         if (desc->materials[i].type == RTGPU_MAT_FRESNELMIX) v.hasFresnelMix = 1;

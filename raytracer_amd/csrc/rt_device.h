@@ -31,6 +31,14 @@ struct DevAreaLight {
     float area;      // Triangle::getSurfaceArea, math/Triangle.h:7-18
 };
 
+struct DevDirectionalLight {
+    float dir[3];   // direction the light travels in
+    float angle;
+    float color[3];
+    float pad;
+    double intensity;
+};
+
 // Everything the kernels need, passed by value as a kernel argument.
 struct SceneView {
     const float4* nodes;        // Node64 records as 4 x float4
@@ -52,7 +60,8 @@ struct SceneView {
     const DevMaterial* materials;
     const DevPointLight* pointLights;
     const DevAreaLight* areaLights;
-    uint32_t nMaterials, nPointLights, nAreaLights;
+    const DevDirectionalLight* dirLights;
+    uint32_t nMaterials, nPointLights, nAreaLights, nDirLights;
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
     float envRadiance[3];

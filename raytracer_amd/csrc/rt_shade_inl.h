@@ -157,7 +157,22 @@ struct NeeSample {
     bool valid;      // a light was chosen (otherwise radiance is black and no ray is needed)
 };
 
-// NextEventEstimation::sample with neePointLight / neeAreaLight, material/NextEventEstimation.cpp:8-120,
+// sampleUniformSteradianSphere, math/Sampler.h:76-88: (0,0,1) turned by rotateX(alpha) * rotateY(beta)
+// (fp64 sines and cosines, math/Transformation.cpp:35-63; the product's third column is
+// (sin b, -sin a cos b, cos a cos b)), then into the basis around `center`.
+__device__ __forceinline__ F3 sample_steradian_sphere(F3 center, float angle, float r0, float r1)
+{
+    const float alpha = (r0 - 0.5f) * 2.0f * angle;
+    const float beta = (r1 - 0.5f) * 2.0f * angle;
+    const double sa = sin((double)alpha), ca = cos((double)alpha), sb = sin((double)beta), cb = cos((double)beta);
+    const F3 l = f3((float)sb, (float)(-sa * cb), (float)(ca * cb));
+    const Basis3 basis = basis_from(center);
+    return f3(basis.u.x * l.x + (basis.v.x * l.y + basis.w.x * l.z),
+              basis.u.y * l.x + (basis.v.y * l.y + basis.w.y * l.z),
+              basis.u.z * l.x + (basis.v.z * l.y + basis.w.z * l.z));
+}
+
+// NextEventEstimation::sample with neePointLight / neeAreaLight / neeDirectionalLight, material/NextEventEstimation.cpp:8-120,
 // and AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41.  The visibility
 // query itself is left to the shadow stage.
 __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int sampleCount,
@@ -168,10 +183,11 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
     out.dir = f3(0, 0, 0);
     out.tmax = 0.0f;
     out.valid = false;
-    const bool hasPoint = sv.nPointLights > 0, hasArea = sv.nAreaLights > 0;
-    const float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f);
+    const bool hasPoint = sv.nPointLights > 0, hasArea = sv.nAreaLights > 0, hasDir = sv.nDirLights > 0;
+    const float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f) + (hasDir ? 1.0f : 0.0f);
     const float pointP = (hasPoint ? 1.0f : 0.0f) / total;
     const float areaP = (hasArea ? 1.0f : 0.0f) / total;
+    const float dirP = (hasDir ? 1.0f : 0.0f) / total;
     const float choice = rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_TYPE);
     if (choice < pointP) {
         const uint32_t n = sv.nPointLights;
@@ -214,6 +230,17 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         out.radiance = rgb_div_f(rgb_scale_d(irr, (double)L.area), areaP * chosenP);
         out.dir = toLamp;
         out.tmax = lampT;
+        out.valid = true;
+    } else if (hasDir) {
+        const uint32_t n = sv.nDirLights;
+        const float chosenP = 1.0f / n;
+        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        if (idx > n - 1) idx = n - 1;
+        const DevDirectionalLight& L = sv.dirLights[idx];
+        out.dir = sample_steradian_sphere(-f3(L.dir[0], L.dir[1], L.dir[2]), L.angle,
+                                          rand_unit(seed, pixel, sample, vertex, DIM_DIR_ALPHA), rand_unit(seed, pixel, sample, vertex, DIM_DIR_BETA));
+        out.radiance = rgb_div_f(rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity), dirP * chosenP);
+        out.tmax = INFINITY;
         out.valid = true;
     }
     return out;

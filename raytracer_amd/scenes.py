@@ -411,6 +411,32 @@ def coat_scene():
     return sc, cam_m, yfov
 
 
+def sun_scene(lights="sun+point"):
+    """Open scene under a directional light (light/DirectionalLight.h): a diffuse floor, a diffuse and a
+    rough glossy sphere, a sky-coloured environment.  lights: "sun" (directional only), "sun+point"
+    (two light types) or "all" (point + area + two directional lights)."""
+    parts = [(*grid_quad((-4, 0, -4), (0, 0, 8), (8, 0, 0), 4, 4), 0)]
+    us = uv_sphere(16, 8)
+    parts.append((us.vertices.astype(np.float64) * 0.8 + np.array([-1.0, 0.8, 0.3]), us.indices, 1))
+    parts.append((us.vertices.astype(np.float64) * 0.6 + np.array([1.1, 0.6, -0.4]), us.indices, 2))
+    sc = SceneData()
+    sc.meshes = [_merge(parts)]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.6, 0.6, 0.55)), MaterialData(MAT_DIFFUSE, (0.7, 0.25, 0.2)),
+                    MaterialData(MAT_GLOSSY, (0.9, 0.9, 0.9), roughness=0.3)]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    d = np.array([-0.35, -1.0, -0.25]); d /= np.linalg.norm(d)
+    sc.directional_lights = [(tuple(d), 0.05, (1.0, 0.97, 0.9), 2.5)]
+    if lights in ("sun+point", "all"):
+        sc.point_lights = [((2.5, 3.0, 2.0), (1.0, 1.0, 1.0), 60.0)]
+    if lights == "all":
+        sc.area_lights = [((-1.0, 3.5, -1.0), (1.0, 3.5, -1.0), (0.0, 3.5, 1.0), (1.0, 0.9, 0.8), 80.0)]
+        d2 = np.array([0.6, -0.7, 0.4]); d2 /= np.linalg.norm(d2)
+        sc.directional_lights.append((tuple(d2), 0.0, (0.3, 0.4, 1.0), 0.8))
+    sc.env = ((0.25, 0.35, 0.5), 1.0)
+    cam_m = look_at((0.3, 2.2, 5.0), (0.0, 0.6, 0.0))
+    return sc, cam_m, 0.8
+
+
 def random_rays(n, lo, hi, seed=0):
     """Incoherent rays: origins uniform in the box [lo,hi], directions uniform on the sphere."""
     rng = np.random.RandomState(seed)

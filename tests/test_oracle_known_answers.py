@@ -208,3 +208,51 @@ def test_transparent_panes_pass_radiance_unchanged_in_expectation():
     assert np.allclose(img.mean(axis=(0, 1)), Lr, rtol=0.02)
     assert img.max(axis=(0, 1))[1] <= 2.0 / (0.99 * 0.99) * 1.0001
     assert stats.extension_rays >= 2 * 0.97 * stats.primary_rays and stats.shadow_rays == 0
+
+
+def test_directional_light_on_a_diffuse_floor_closed_form():
+    """neeDirectionalLight (material/NextEventEstimation.cpp:55-67) with angle 0: every next-event sample
+    sees irradiance color * intensity from straight above; DiffuseMaterial::bsdf turns a sample into
+    albedo * E * cos / pi * 2 and half of the paths take it, so a pixel of the open floor converges to
+    albedo * E / pi (bounce paths leave the scene; no environment)."""
+    from raytracer_amd.abi import MAT_DIFFUSE, InstanceData, MaterialData, MeshData, SceneData
+    v = np.array([[-50, 0, -50], [-50, 0, 50], [50, 0, 50], [50, 0, -50]], np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3]], np.uint32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (4, 1))
+    sc = SceneData()
+    sc.meshes = [MeshData(v, nrm, idx)]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.8, 0.5, 0.2))]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    sc.directional_lights = [((0.0, -1.0, 0.0), 0.0, (1.0, 0.5, 0.25), 3.0)]
+    cam_m = scenes.look_at((0.0, 5.0, 0.0), (0.0, 0.0, 0.1))
+    cam = oracle.camera_from_transform(40.0, cam_m)
+    img, stats = oracle.OracleScene(sc).render(cam, abi.make_settings(16, 12, geometry_aa=16, material_aa=16, seed=9))
+    want = np.array([0.8, 0.5, 0.2]) * np.array([1.0, 0.5, 0.25]) * 3.0 / np.pi
+    assert np.allclose(img.mean(axis=(0, 1)), want, rtol=0.03)
+    # each sample is 0 or albedo * E * 2 / pi (RGB float rounding aside)
+    assert img.max() <= want.max() * 2 * 1.001
+    assert stats.shadow_rays > 0.4 * 16 * 12 * 256
+
+
+def test_directional_light_cone_stays_inside_its_angle():
+    """sampleUniformSteradianSphere (math/Sampler.h:76-88): directions are unit vectors within
+    sqrt(2) * angle of the axis (two rotations by at most `angle`)."""
+    from raytracer_amd.abi import MAT_DIFFUSE, InstanceData, MaterialData, MeshData, SceneData
+    # a small occluder straight above the floor point under the camera blocks the light only when the
+    # cone is narrow: narrow cone -> black centre, wide cone -> partially lit
+    v = np.array([[-50, 0, -50], [-50, 0, 50], [50, 0, 50], [50, 0, -50],
+                  [-0.5, 2, -0.5], [-0.5, 2, 0.5], [0.5, 2, 0.5], [0.5, 2, -0.5]], np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3], [4, 6, 5], [4, 7, 6]], np.uint32)
+    nrm = np.tile(np.array([[0, 1, 0]], np.float32), (8, 1))
+    means = []
+    for angle in (0.01, 0.6):
+        sc = SceneData()
+        sc.meshes = [MeshData(v, nrm, idx)]
+        sc.materials = [MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0))]
+        sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+        sc.directional_lights = [((0.0, -1.0, 0.0), angle, (1.0, 1.0, 1.0), 1.0)]
+        cam = oracle.camera_from_transform(2.0, scenes.look_at((0.0, 1.0, 0.0), (0.0, 0.0, 0.001)))
+        # path length 2: direct light only (a bounce ends at the last vertex, which contributes nothing)
+        img, _ = oracle.OracleScene(sc).render(cam, abi.make_settings(4, 4, geometry_aa=16, material_aa=16, max_path_length=2, seed=2))
+        means.append(float(img.mean()))
+    assert means[0] == 0.0 and 0.02 < means[1] < 1.0 / np.pi
