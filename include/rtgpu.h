@@ -156,8 +156,9 @@ typedef struct rtgpu_camera {
     float v[3];
     float w[3];
     double width;
-    double aperture;       /* 0 = pinhole */
-    double focal_distance;
+    double aperture;       /* 0 = pinhole; > 0: lens radius of the thin-lens model (camera/PerspectiveCamera.cpp:39-51,
+                            * needs geometry_aa >= 2) */
+    double focal_distance; /* distance along the pinhole ray at which lens rays converge */
 } rtgpu_camera;
 
 typedef enum rtgpu_jitter_mode {

@@ -1297,14 +1297,37 @@ RGBf path_energy(const orc_scene& S, const std::vector<TransportNode>& path)
     return energy;
 }
 
-// PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52 (aperture 0)
+// sampleUniformStratifiedCube, math/Sampler.h:28-41
+V3 stratified_cube(float level, float sampleI, V3 r)
+{
+    float binsPerAxis = std::pow(level, 1.0f / 3.0f);
+    float oneOverBinsPerAxis = 1.0f / binsPerAxis;
+    float binX = std::fmod(sampleI, binsPerAxis);
+    float binY = std::floor(std::fmod(sampleI, binsPerAxis * binsPerAxis) * oneOverBinsPerAxis);
+    float binZ = std::floor(std::fmod(sampleI, level) * (oneOverBinsPerAxis * oneOverBinsPerAxis));
+    return V3{(binX * oneOverBinsPerAxis) + (r.x * oneOverBinsPerAxis),
+              (binY * oneOverBinsPerAxis) + (r.y * oneOverBinsPerAxis),
+              (binZ * oneOverBinsPerAxis) + (r.z * oneOverBinsPerAxis)};
+}
+// sampleUniformCircle(radius, rand1, rand2, rand3), math/Sampler.h:90-103
+void uniform_circle(float radius, V3 r, float& x, float& y)
+{
+    float angle = r.x * 2.0f * M_PI;
+    float dist = (r.y * radius) + (r.z * radius);
+    if (dist > radius) dist = (2.0f * radius) - dist;
+    x = std::cos(angle) * dist;
+    y = std::sin(angle) * dist;
+}
+
+// PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52
 void camera_ray(const rtgpu_camera& cam, int px, int py, int W, int H, int aaLevel, int sampleI, int jitterMode, const RandCtx& rc, V3& o, V3& d)
 {
-    float r0, r1;
-    if (jitterMode == RTGPU_JITTER_CENTER) { r0 = 0.5f; r1 = 0.5f; }
-    else { r0 = rc.unit(0); r1 = rc.unit(1); }
+    const bool random = jitterMode != RTGPU_JITTER_CENTER;
+    float r0 = 0.5f, r1 = 0.5f;
+    if (random) { r0 = rc.unit(0); r1 = rc.unit(1); }
+    float apertureSamplesPerSensorSample = cam.aperture > 0 ? std::min(8, aaLevel / 2) : 1.0f;
     float sx, sy;
-    stratified_square((int)(aaLevel / 1.0f), sampleI / 1.0f, r0, r1, sx, sy);
+    stratified_square((int)(aaLevel / apertureSamplesPerSensorSample), sampleI / apertureSamplesPerSensorSample, r0, r1, sx, sy);
     sx = (float)px + sx;
     sy = (float)py + sy;
     double height = H * cam.width / W;
@@ -1314,6 +1337,19 @@ void camera_ray(const rtgpu_camera& cam, int px, int py, int W, int H, int aaLev
     V3 dir = ((U * (float)u) + (V * (float)v)) - Wv;
     d = normalized(dir);
     o = mk(cam.origin);
+    if (cam.aperture == 0) return;
+    V3 focalPlanePoint = o + (d * (float)cam.focal_distance);
+    V3 r{0.5f, 0.5f, 0.5f};
+    if (random) r = V3{rc.unit(2), rc.unit(3), rc.unit(4)};
+    // sampleUniformStratifiedCircle(float radius, int level, int sampleI), math/Sampler.h:110-114
+    V3 cube = stratified_cube((float)(int)apertureSamplesPerSensorSample, (float)(int)std::fmod((double)sampleI, (double)apertureSamplesPerSensorSample), r);
+    float ox, oy;
+    uniform_circle((float)cam.aperture, cube, ox, oy);
+    V3 lensPoint = o;
+    lensPoint = lensPoint + (U * ox);
+    lensPoint = lensPoint + (V * oy);
+    o = lensPoint;
+    d = normalized(focalPlanePoint - lensPoint);
 }
 
 // RenderTileTask::execute for one pixel, renderer/Renderer.cpp:135-267

@@ -580,7 +580,9 @@ int rtgpu_generate_primary_device(const rtgpu_camera* camera, const rtgpu_render
 {
     if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
     if (int rc = check_settings(settings)) return rc;
-    if (camera->aperture != 0.0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "thin-lens cameras (aperture > 0) are not supported");
+    // thin lens: min(8, aaLevel / 2) lens samples per sensor sample, a divisor (camera/PerspectiveCamera.cpp:28-29)
+    if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
     if (!d_origins || !d_dirs) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray buffer");
     RT_HIP(rt::launch_generate_primary(*camera, *settings, sample_index, d_origins, d_dirs, (hipStream_t)hip_stream));
     return RTGPU_OK;
@@ -592,7 +594,9 @@ int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera, co
     if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
     if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
     if (int rc = check_settings(settings)) return rc;
-    if (camera->aperture != 0.0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "thin-lens cameras (aperture > 0) are not supported");
+    // thin lens: min(8, aaLevel / 2) lens samples per sensor sample, a divisor (camera/PerspectiveCamera.cpp:28-29)
+    if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
     if (!d_rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
     RT_HIP(hipSetDevice(scene->device));
     std::string err;

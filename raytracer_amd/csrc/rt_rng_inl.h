@@ -12,7 +12,7 @@
 namespace rt {
 
 enum RngDim : uint32_t {
-    DIM_CAM_X = 0, DIM_CAM_Y = 1,
+    DIM_CAM_X = 0, DIM_CAM_Y = 1, DIM_LENS_X = 2, DIM_LENS_Y = 3, DIM_LENS_Z = 4,   // with vertex = kVertexCamera
     DIM_NEE_CHOICE = 1, DIM_LIGHT_TYPE = 2, DIM_LIGHT_INDEX = 3, DIM_AREA_U = 4, DIM_AREA_V = 5,
     DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_MIX0 = 12
 };
@@ -46,19 +46,46 @@ __device__ __forceinline__ void stratified_square(int level, float sampleI, floa
     sy = (binY / binsPerAxis) + (r1 / binsPerAxis);
 }
 
-// PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52 (pinhole: aperture == 0).
+// sampleUniformStratifiedCube, math/Sampler.h:28-41 (r = the three Rand::unit() draws).
+__device__ __forceinline__ F3 stratified_cube(float level, float sampleI, F3 r)
+{
+    const float binsPerAxis = powf(level, 1.0f / 3.0f);
+    const float oneOverBinsPerAxis = 1.0f / binsPerAxis;
+    const float binX = fmodf(sampleI, binsPerAxis);
+    const float binY = floorf(fmodf(sampleI, binsPerAxis * binsPerAxis) * oneOverBinsPerAxis);
+    const float binZ = floorf(fmodf(sampleI, level) * (oneOverBinsPerAxis * oneOverBinsPerAxis));
+    return f3((binX * oneOverBinsPerAxis) + (r.x * oneOverBinsPerAxis),
+              (binY * oneOverBinsPerAxis) + (r.y * oneOverBinsPerAxis),
+              (binZ * oneOverBinsPerAxis) + (r.z * oneOverBinsPerAxis));
+}
+
+// sampleUniformCircle(radius, rand1, rand2, rand3), math/Sampler.h:90-103.
+__device__ __forceinline__ void uniform_circle(float radius, F3 r, float& x, float& y)
+{
+    const float angle = (float)(r.x * 2.0f * 3.14159265358979323846);
+    float dist = (r.y * radius) + (r.z * radius);
+    if (dist > radius) dist = (2.0f * radius) - dist;
+    x = cosf(angle) * dist;
+    y = sinf(angle) * dist;
+}
+
+// PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52: pinhole, or thin lens when
+// aperture > 0 (the caller guarantees geometry_aa >= 2 then: the reference divides by aaLevel / 2).
 __device__ __forceinline__ void camera_ray(const rtgpu_camera& cam, const rtgpu_render_settings& st, int x, int y,
                                            int sampleIndex, F3& o, F3& d)
 {
     const uint32_t pixel = (uint32_t)(y * st.width + x);
+    const uint32_t sample = (uint32_t)(sampleIndex * st.material_aa);
+    const bool random = st.jitter_mode == RTGPU_JITTER_RANDOM;
     float r0 = 0.5f, r1 = 0.5f;
-    if (st.jitter_mode == RTGPU_JITTER_RANDOM) {
-        const uint32_t sample = (uint32_t)(sampleIndex * st.material_aa);
+    if (random) {
         r0 = rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_CAM_X);
         r1 = rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_CAM_Y);
     }
+    const int aaLevel = st.geometry_aa;
+    const float apertureSamples = cam.aperture > 0 ? (float)min(8, aaLevel / 2) : 1.0f;
     float sx, sy;
-    stratified_square(st.geometry_aa, (float)sampleIndex, r0, r1, sx, sy);
+    stratified_square((int)(aaLevel / apertureSamples), sampleIndex / apertureSamples, r0, r1, sx, sy);
     sx = (float)x + sx;
     sy = (float)y + sy;
     const double height = st.height * cam.width / st.width;
@@ -68,6 +95,21 @@ __device__ __forceinline__ void camera_ray(const rtgpu_camera& cam, const rtgpu_
     const F3 dir = ((U * (float)u) + (V * (float)v)) - W;
     d = normalized3(dir);
     o = f3(cam.origin[0], cam.origin[1], cam.origin[2]);
+    if (cam.aperture == 0) return;
+    const F3 focalPlanePoint = o + (d * (float)cam.focal_distance);
+    F3 r = f3(0.5f, 0.5f, 0.5f);
+    if (random) {
+        r = f3(rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_LENS_X), rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_LENS_Y),
+               rand_unit(st.seed, pixel, sample, kVertexCamera, DIM_LENS_Z));
+    }
+    const F3 cube = stratified_cube((float)(int)apertureSamples, (float)(int)fmod((double)sampleIndex, (double)apertureSamples), r);
+    float ox, oy;
+    uniform_circle((float)cam.aperture, cube, ox, oy);
+    F3 lensPoint = o;
+    lensPoint = lensPoint + (U * ox);
+    lensPoint = lensPoint + (V * oy);
+    o = lensPoint;
+    d = normalized3(focalPlanePoint - lensPoint);
 }
 
 } // namespace rt

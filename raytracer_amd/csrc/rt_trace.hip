@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64) void trace_any_kernel(SceneView sv, const float
     occ[i] = hit ? 1 : 0;
 }
 
-// PerspectiveCamera::generateRay (camera/PerspectiveCamera.cpp:26-52), aperture 0.
+// PerspectiveCamera::generateRay (camera/PerspectiveCamera.cpp:26-52).
 __global__ __launch_bounds__(256) void generate_primary_kernel(rtgpu_camera cam, rtgpu_render_settings st, int sampleIndex,
                                                                float* __restrict__ ro, float* __restrict__ rd)
 {

@@ -168,6 +168,41 @@ def test_primary_ray_generation_matches_oracle():
             assert np.abs(d_d.cpu().numpy() - rd).max() <= 1.2e-7  # sqrt/divide are correctly rounded on both sides
 
 
+def test_thin_lens_rays_match_oracle():
+    """PerspectiveCamera::generateRay with aperture > 0 (camera/PerspectiveCamera.cpp:39-51): lens points and
+    directions agree with the oracle to float rounding (powf / cosf / sinf of device and host libm)."""
+    import torch
+    sc, cam_m, yfov = scenes.box_scene()
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, 48 / 36), cam_m)
+    cam.aperture, cam.focal_distance = 0.08, 2.5
+    for jitter, G in ((abi.JITTER_RANDOM, 4), (abi.JITTER_RANDOM, 16), (abi.JITTER_RANDOM, 36), (abi.JITTER_CENTER, 16)):
+        st = abi.make_settings(48, 36, geometry_aa=G, material_aa=2, seed=7, jitter_mode=jitter)
+        for si in (0, 1, G // 2, G - 1):
+            d_o = torch.empty((48 * 36, 3), dtype=torch.float32, device="cuda")
+            d_d = torch.empty((48 * 36, 3), dtype=torch.float32, device="cuda")
+            api.generate_primary_device(cam, st, si, d_o, d_d, torch.cuda.current_stream())
+            torch.cuda.synchronize()
+            ro, rd = oracle.generate_primary(cam, st, si)
+            assert np.abs(d_o.cpu().numpy() - ro).max() <= 2e-6
+            assert np.abs(d_d.cpu().numpy() - rd).max() <= 2e-6
+    with pytest.raises(ValueError):   # min(8, aaLevel / 2) = 0 lens samples: the reference divides by it
+        api.generate_primary_device(cam, abi.make_settings(8, 8, geometry_aa=1, material_aa=1), 0, d_o, d_d, torch.cuda.current_stream())
+
+
+def test_render_with_thin_lens_matches_oracle():
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 48, 36
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    cam.aperture, cam.focal_distance = 0.06, 2.4
+    st = abi.make_settings(W, H, geometry_aa=8, material_aa=4, seed=4)
+    ref, rstats = oracle.OracleScene(sc).render(cam, st)
+    with api.Scene(sc) as g:
+        img, stats = api.Renderer().render(g, cam, st)
+    assert np.isfinite(img).all()
+    assert rel_rmse(img, ref) <= 2e-3   # lens points differ in the last bits, which can flip single hit decisions
+    assert stats.primary_rays == rstats.primary_rays
+
+
 def rel_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / max(float(np.mean(b)), 1e-12))
 

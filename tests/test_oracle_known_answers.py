@@ -256,3 +256,46 @@ def test_directional_light_cone_stays_inside_its_angle():
         img, _ = oracle.OracleScene(sc).render(cam, abi.make_settings(4, 4, geometry_aa=16, material_aa=16, max_path_length=2, seed=2))
         means.append(float(img.mean()))
     assert means[0] == 0.0 and 0.02 < means[1] < 1.0 / np.pi
+
+
+def test_thin_lens_rays_meet_the_pinhole_ray_on_the_focal_plane():
+    """camera/PerspectiveCamera.cpp:39-51: the lens point lies within `aperture` of the camera origin in
+    the sensor plane, and every lens ray passes through the point the pinhole ray reaches at the focal
+    distance (pinhole and lens rays of one sample share their sensor position only when the sensor
+    jitter is the same: JITTER_CENTER)."""
+    cam_m = scenes.look_at((0.5, 1.0, 4.0), (0.0, 0.5, 0.0))
+    pin = oracle.camera_from_transform(50.0, cam_m)
+    lens = oracle.camera_from_transform(50.0, cam_m)
+    lens.aperture, lens.focal_distance = 0.1, 3.0
+    # geometry_aa 16 -> 8 lens samples per sensor sample, 2 sensor strata: sensor jitter differs between
+    # the two cameras, so compare within the lens camera: samples 0..7 share one sensor stratum
+    st = abi.make_settings(24, 18, geometry_aa=16, material_aa=1, seed=3, jitter_mode=abi.JITTER_CENTER)
+    rays = [oracle.generate_primary(lens, st, i) for i in range(8)]
+    origin = np.array(list(lens.origin), np.float32)
+    U, V = np.array(list(lens.u)), np.array(list(lens.v))
+    focal = None
+    for o, d in rays:
+        off = o - origin[None, :]
+        assert np.all(np.hypot(off @ U, off @ V) <= 0.1 * 1.0001)      # inside the aperture
+        assert np.abs(off @ np.array(list(lens.w))).max() < 1e-6          # in the sensor plane
+        # where the ray crosses the plane at focal distance along the pinhole direction: reconstruct the
+        # common point as the least-squares intersection below
+        focal = (o, d) if focal is None else focal
+    # all 8 rays of a pixel meet in one point
+    o0, d0 = rays[0]
+    for o, d in rays[1:]:
+        w0 = o0 - o
+        a, b, c = (d0 * d0).sum(1), (d0 * d).sum(1), (d * d).sum(1)
+        dd, e = (d0 * w0).sum(1), (d * w0).sum(1)
+        den = a * c - b * b
+        ok = den > 1e-10
+        if not ok.any():   # the folded radius (dist > radius -> 2 radius - dist) makes some strata coincide
+            assert np.array_equal(o, o0)
+            continue
+        sc_ = (b * e - c * dd)[ok] / den[ok]
+        tc = (a * e - b * dd)[ok] / den[ok]
+        gap = np.linalg.norm((o0[ok] + d0[ok] * sc_[:, None]) - (o[ok] + d[ok] * tc[:, None]), axis=1)
+        assert gap.max() < 1e-4
+        assert np.allclose(sc_, 3.0, rtol=2e-2)                          # at about the focal distance
+    po, pd = oracle.generate_primary(pin, st, 0)
+    assert np.array_equal(po, np.tile(origin, (24 * 18, 1)))
