@@ -1,0 +1,60 @@
+"""The C ABI driven from a C++ host program (examples/cxx_host.cpp, built by `make -C examples`): the
+same small scene is rebuilt here through the Python mirror and must give the same hits and the same
+frame bit for bit; the frame travels as a TILE file (io/TileFile.cpp:8-27)."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from raytracer_amd import abi, api, scenes, tilefile
+from raytracer_amd.abi import MAT_DIFFUSE, MAT_GLOSSY, SHAPE_SPHERE, InstanceData, MaterialData, MeshData, SceneData
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "examples", "cxx_host")
+
+
+def host_scene():
+    v = np.array([[-4, 0, -4], [-4, 0, 4], [4, 0, 4], [4, 0, -4],
+                  [-4, 0, -4], [4, 0, -4], [4, 5, -4], [-4, 5, -4],
+                  [-1, 0, 1.5], [1, 0, 1.5], [1, 0, 3.5], [-1, 0, 3.5], [0, 1.5, 2.5]], np.float32)
+    n = np.array([[0, 1, 0]] * 4 + [[0, 0, 1]] * 4 +
+                 [[-0.5, 0.5, -0.5], [0.5, 0.5, -0.5], [0.5, 0.5, 0.5], [-0.5, 0.5, 0.5], [0, 1, 0]], np.float32)
+    idx = np.array([[0, 1, 2], [0, 2, 3], [4, 5, 6], [4, 6, 7], [8, 12, 9], [9, 12, 10], [10, 12, 11], [11, 12, 8]], np.uint32)
+    sc = SceneData()
+    sc.meshes = [MeshData(v, n, idx, np.array([0, 0, 1, 1, 2, 2, 2, 2], np.uint32))]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.7, 0.7, 0.65)), MaterialData(MAT_DIFFUSE, (0.25, 0.35, 0.7)),
+                    MaterialData(MAT_GLOSSY, (0.9, 0.85, 0.8), roughness=0.3), MaterialData(MAT_DIFFUSE, (0.8, 0.3, 0.2))]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4)),
+                    InstanceData(SHAPE_SPHERE, 3, scenes.translate(-2, 1, 0), scenes.translate(2, -1, 0)),
+                    InstanceData(SHAPE_SPHERE, 3, scenes.translate(2, 1, 0), scenes.translate(-2, -1, 0))]
+    sc.point_lights = [((1.0, 4.0, 3.0), (1.0, 1.0, 1.0), 120.0)]
+    cam_m = np.array([[1, 0, 0, 0], [0, 1, 0, 2], [0, 0, 1, 7], [0, 0, 0, 1]], np.float64)
+    return sc, cam_m
+
+
+def test_cxx_host_program_matches_the_python_mirror(tmp_path):
+    if not os.path.exists(EXE):
+        pytest.fail("examples/cxx_host is missing: build it with `make -C examples`")
+    W, H, G, M, seed = 64, 48, 4, 4, 7
+    out = str(tmp_path / "host.tile")
+    log = subprocess.run([EXE, out, str(W), str(H), str(G), str(M), str(seed)], check=True, capture_output=True, text=True, timeout=120).stdout
+    # Scene::traceRay as in raytracer/test/BVH.cpp:18-49 (instances 1 and 2 are the spheres at x = -2 / +2)
+    assert "traceRay -x: inst 1 t 1\n" in log and "traceRay +x: inst 2 t 1\n" in log and "traceRay +y: miss" in log
+    assert "testVisibility -x within 0.5: 0, within 2: 1" in log
+    assert "invalid_argument: scene has no materials" in log
+    m = re.search(r"render 64x48: (\d+) primary, (\d+) extension, (\d+) shadow rays, .* (\d+) progress calls", log)
+    assert m and int(m.group(1)) == W * H * G and int(m.group(4)) >= 2
+    w, h, tile, px = tilefile.read_tile_file(out)
+    assert (w, h, tile) == (W, H, (0, 0, W, H))
+
+    sc, cam_m = host_scene()
+    cam = api.camera_from_transform(55.0, cam_m)
+    st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=10, seed=seed)
+    with api.Scene(sc) as g:
+        img, stats = api.Renderer().render(g, cam, st)
+    assert [int(m.group(1)), int(m.group(2)), int(m.group(3))] == [stats.primary_rays, stats.extension_rays, stats.shadow_rays]
+    assert np.array_equal(px, img)
+    assert img.mean() > 0.01 and np.isfinite(img).all()

@@ -139,6 +139,17 @@ def test_empty_and_ragged_batches():
             assert_hits_match(S, g.trace_rays(o, d), o, d)
         with pytest.raises(ValueError):
             g.trace_rays(np.zeros((3, 3), np.float32), np.zeros((2, 3), np.float32))
+    # single-mesh scene: the wave-cooperative kernels with their interleaved ray order
+    sc, _, _ = scenes.box_scene()
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        assert g.trace_rays(np.zeros((0, 3), np.float32), np.zeros((0, 3), np.float32)).shape == (0,)
+        for n in (1, 7, 63, 64, 65, 511, 512, 513, 1000, 4097):
+            o, d = scenes.random_rays(n, (0.2, 0.2, 0.2), (3.8, 3.8, 3.8), seed=100 + n)
+            got = g.trace_rays(o, d)
+            assert_hits_match(S, got, o, d)
+            tmax = np.where(np.arange(n) % 2 == 0, got["t"] * 0.5, got["t"] * 1.5).astype(np.float32)
+            assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
 
 
 def test_degenerate_rays_axis_aligned_and_zero_components():
