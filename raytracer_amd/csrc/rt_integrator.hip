@@ -10,7 +10,7 @@
 //             shadow ray, or ends the path.  The first shade pass of a batch runs one lane per
 //             path (pixel, i, material sample j) and takes vertex 0 from the sample's primary hit
 //   shadow  : any-hit query; an unoccluded path receives its pending contribution
-//   extend  : closest-hit query for the extension rays
+//   extend  : closest-hit query for the extension rays (one launch carries both: trace_stage_kernel)
 //   resolve : per pixel, sums the path values in the reference's order and writes the frame buffer
 //
 // Queues hold path indices and are filled with wave-aggregated appends (one atomic per wave:
@@ -504,13 +504,14 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
     if (rep != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)rep) - 1)) atomicAdd(pool.counters + 3, (uint32_t)__popcll(rep));
 }
 
-// ---- shadow / connect --------------------------------------------------------------------------
+// ---- shadow / connect and extend ------------------------------------------------------------------
+// Both run after a shade pass and are independent of each other, so one launch carries both: the
+// first workgroups trace the extension rays (closest hit), the rest the shadow rays (any hit).
 template <bool INSTANCED>
-__global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uint32_t n)
+__device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& pool, uint32_t block, uint32_t n,
+                                             typename TraceLds<INSTANCED>::type& lds, int lane)
 {
-    __shared__ typename TraceLds<INSTANCED>::type lds;
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x * 64u + lane;
+    const uint32_t q = block * 64u + lane;
     const bool has = q < n;
     const uint32_t p = pool.qShadow[has ? q : 0u];
     const float4 ra = pool.rayA[p], rb = pool.rayB[p];
@@ -518,13 +519,11 @@ __global__ __launch_bounds__(64) void shadow_kernel(SceneView sv, Pool pool, uin
     if (has && !occluded) pool.result[p] = pool.aux[p];
 }
 
-// ---- extend --------------------------------------------------------------------------------------
 template <bool INSTANCED>
-__global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ queue, uint32_t n)
+__device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& pool, const uint32_t* __restrict__ queue, uint32_t block,
+                                             uint32_t n, typename TraceLds<INSTANCED>::type& lds, int lane)
 {
-    __shared__ typename TraceLds<INSTANCED>::type lds;
-    const int lane = threadIdx.x;
-    const uint32_t q = blockIdx.x * 64u + lane;
+    const uint32_t q = block * 64u + lane;
     const bool has = q < n;
     const uint32_t p = queue[has ? q : 0u];
     const float4 ra = pool.rayA[p], rb = pool.rayB[p];
@@ -532,6 +531,16 @@ __global__ __launch_bounds__(64) void extend_kernel(SceneView sv, Pool pool, con
     if (!has) return;
     pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
     if (INSTANCED) pool.hitInst[p] = r.inst;
+}
+
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, uint32_t nExt, uint32_t nShadow)
+{
+    __shared__ typename TraceLds<INSTANCED>::type lds;
+    const int lane = threadIdx.x;
+    const uint32_t extBlocks = (nExt + 63u) / 64u;
+    if (blockIdx.x < extBlocks) extend_block<INSTANCED>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
+    else shadow_block<INSTANCED>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
@@ -703,13 +712,10 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                 LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
                 LN_TRY(hipStreamSynchronize(ls));
                 const uint32_t nExt = h[0], nShadow = h[1], nRepeated = h[3];
-                if (nShadow) {
-                    if (single) hipLaunchKernelGGL((shadow_kernel<false>), dim3((nShadow + 63) / 64), dim3(64), 0, ls, sv, pool, nShadow);
-                    else hipLaunchKernelGGL((shadow_kernel<true>), dim3((nShadow + 63) / 64), dim3(64), 0, ls, sv, pool, nShadow);
-                }
-                if (nExt) {
-                    if (single) hipLaunchKernelGGL((extend_kernel<false>), dim3((nExt + 63) / 64), dim3(64), 0, ls, sv, pool, qOut, nExt);
-                    else hipLaunchKernelGGL((extend_kernel<true>), dim3((nExt + 63) / 64), dim3(64), 0, ls, sv, pool, qOut, nExt);
+                if (nShadow || nExt) {
+                    const uint32_t blocks = (nExt + 63) / 64 + (nShadow + 63) / 64;
+                    if (single) hipLaunchKernelGGL((trace_stage_kernel<false>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
+                    else hipLaunchKernelGGL((trace_stage_kernel<true>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
                 }
                 ln.extension += nExt - nRepeated;
                 ln.shadow += nShadow;
