@@ -152,6 +152,39 @@ def test_empty_and_ragged_batches():
             assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
 
 
+def test_deep_stack_rays_along_a_row_of_triangles():
+    """Rays that pierce every box of a deep tree (524 288 small triangles in a row, rays along the row) need
+    more pending subtrees than the LDS part of the traversal stack holds: the private-memory overflow path
+    of both kernels (cooperative: single mesh; per-lane: two instances) must give the oracle's answers."""
+    n = 1 << 19
+    x = np.arange(n, dtype=np.float64) * 0.01
+    v = np.empty((n, 3, 3), np.float64)
+    v[:, 0] = np.stack([x, np.full(n, -0.5), np.full(n, -0.5)], 1)
+    v[:, 1] = np.stack([x, np.full(n, 0.5), np.full(n, -0.5)], 1)
+    v[:, 2] = np.stack([x + 0.002, np.zeros(n), np.full(n, 0.6)], 1)
+    verts = v.reshape(-1, 3).astype(np.float32)
+    idx = np.arange(3 * n, dtype=np.uint32).reshape(n, 3)
+    nrm = np.tile(np.array([[1, 0, 0]], np.float32), (3 * n, 1))
+    rng = np.random.RandomState(5)
+    m = 256
+    o = np.stack([np.where(np.arange(m) % 2 == 0, -1.0, n * 0.01 + 1.0), rng.uniform(-0.15, 0.15, m), rng.uniform(-0.3, 0.1, m)], 1).astype(np.float32)
+    d = np.stack([np.where(np.arange(m) % 2 == 0, 1.0, -1.0), rng.uniform(-1e-4, 1e-4, m), rng.uniform(-1e-4, 1e-4, m)], 1)
+    d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+    for instances in (1, 2):
+        sc = abi.SceneData()
+        sc.meshes = [abi.MeshData(verts, nrm, idx)]
+        sc.materials = [abi.MaterialData(abi.MAT_DIFFUSE, (0.7, 0.7, 0.7))]
+        sc.instances = [abi.InstanceData(0, 0, scenes.translate(0, 3.0 * k, 0), scenes.translate(0, -3.0 * k, 0)) for k in range(instances)]
+        S = oracle.OracleScene(sc)
+        with api.Scene(sc) as g:
+            assert g.info().max_depth >= 17   # more than the 14 (cooperative) / 16 (per-lane) LDS stack entries
+            got = g.trace_rays(o, d)
+            assert (got["inst"] != abi.INVALID_ID).all()
+            assert_hits_match(S, got, o, d)
+            tmax = (got["t"] * np.where(np.arange(m) % 3 == 0, 0.999, 1.5)).astype(np.float32)
+            assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
+
+
 def test_degenerate_rays_axis_aligned_and_zero_components():
     """Directions with exact zeros (1/d = inf in the slab test) and rays starting on geometry."""
     sc, _, _ = scenes.box_scene()
