@@ -36,6 +36,24 @@ def bench_frame(torch, dist, dev, rank, world, frames=3):
     scene = api.Scene(sc)
     st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1)
     bpr = 1 if world == 1 else 4
+    # pre-flight on every rank before any collective of this section: a rank that cannot render must
+    # not leave the others waiting in the gather
+    ok = 1.0
+    try:
+        probe = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        api.Renderer().render_device(scene, cam, abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1,
+                                                                  tile=(0, 0, 64, 8)), probe, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+    except Exception as e:  # noqa: BLE001
+        ok = 0.0
+        sys.stderr.write("frame pre-flight failed on rank %d: %s\n" % (rank, e))
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = float(flag.item())
+    if ok == 0.0:
+        scene.close()
+        return {"error": "frame pre-flight failed on some rank (see stderr)"}
     times, rays = [], 0
     for k in range(frames + 1):  # the first frame is the warm-up
         torch.cuda.synchronize()

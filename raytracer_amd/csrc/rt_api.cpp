@@ -217,7 +217,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         std::memcpy(di.inv, id.inverse, sizeof(double) * 12);
         di.shape = id.shape;
         di.material = id.material;
-        di.root = 0; di.triBase = 0; di.meshVertBase = 0; di.pad = 0;
+        di.root = 0; di.triBase = 0; di.meshVertBase = 0; di.keyBase = 0;
         // InstancedModelList::getAABB (shape/list/InstancedModelList.cpp:21-26) =
         // AABB::getAABBOfTransformed (shape/AABB.cpp:33-46) of the shape's box; a sphere declares
         // +-0.5 (shape/Sphere.cpp:11-14)
@@ -365,6 +365,16 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
             inst[i].triBase = meshTriBase[inst[i].shape];
         }
     }
+    // tie-break keys of the cooperative instanced traversal: (instance, triangle) -> keyBase[instance] + triangle
+    bool coopInstanced = !refTop && !hasSphere && nInst > 1;
+    {
+        uint64_t running = 0;
+        for (uint32_t i = 0; i < nInst && coopInstanced; ++i) {
+            inst[i].keyBase = (uint32_t)running;
+            running += desc->meshes[inst[i].shape].n_triangles;
+            if (running >= 0xFFFFFFFFull) coopInstanced = false;   // keys would not fit: the per-lane kernel handles the scene
+        }
+    }
     // ---- materials and lights --------------------------------------------------------------
     std::vector<DevMaterial> mats(desc->n_materials);
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
@@ -433,6 +443,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.topRoot = topRoot;
     v.singleMesh = singleMesh ? 1u : 0u;
     v.refTop = refTop ? 1u : 0u;
+    v.coopInstanced = coopInstanced ? 1u : 0u;
     if (singleMesh) {
         static const double ident[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
         bool same = true;

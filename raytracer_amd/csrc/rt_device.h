@@ -50,6 +50,7 @@ struct SceneView {
     uint32_t topRoot;           // first node of the top-level tree
     uint32_t singleMesh;        // 1: exactly one instance and it is a mesh (no top-level tree walk)
     uint32_t identityXf;        // singleMesh and the instance's world->object transform is exactly the identity
+    uint32_t coopInstanced;     // several mesh instances, no sphere, keys fit 32 bits: cooperative instanced traversal
     uint32_t refTop;            // 1: top-level tree, child order and early exit follow the reference exactly (scenes with spheres)
     int32_t refTopRoot;         // refTop: 0 (inner root) or the leaf reference when the whole list is one leaf
     int32_t stealMinIdle;       // idle lanes a wave needs before it runs a work-stealing round

@@ -127,8 +127,10 @@ __device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool pre
 // per-lane stack otherwise.
 template <bool INSTANCED>
 struct TraceLds {
-    struct Plain { int stack[kLdsStack][64]; };
-    using type = Plain;
+    union type {   // per-lane stack (reference-order walk, scenes whose keys do not fit) or the cooperative state
+        int stack[kLdsStack][64];
+        StealLdsInst<false> coop;
+    };
 };
 template <>
 struct TraceLds<false> {
@@ -147,6 +149,7 @@ __device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool ha
     } else {
         TraceResult r;
         r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
+        if (sv.coopInstanced) return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
         if (!has) return r;
         if (sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, lds.stack, lane, nb, nt);
         return trace_ray<true, false, false>(sv, o, d, INFINITY, lds.stack, lane, nb, nt);
@@ -159,6 +162,7 @@ __device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3
     if constexpr (!INSTANCED) {
         return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
     } else {
+        if (sv.coopInstanced) return trace_wave_steal_inst<true, false>(sv, has, o, d, tmax, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
         if (!has) return false;
         if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);
         return trace_ray<true, true, false>(sv, o, d, tmax, lds.stack, lane, nb, nt).inst != kInvalid;

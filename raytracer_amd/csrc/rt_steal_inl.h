@@ -20,8 +20,8 @@
 // test (same operands, same result bits) once per ray after the traversal, which keeps the LDS
 // block at 4.5 KB.
 //
-// Single-mesh scenes only (the benchmark and render workloads are triangle soups); instanced
-// scenes use trace_ray().
+// trace_wave_steal() serves single-mesh scenes (triangle soups), trace_wave_steal_inst() scenes of
+// several mesh instances; scenes with analytic spheres use the per-lane walks of rt_trace_inl.h.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -265,6 +265,227 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
         if (lane == 7) nTris = (uint32_t)wall_clock64();
     }
 #endif
+    return r;
+}
+
+// ---- instanced scenes ------------------------------------------------------------------------
+//
+// The same scheme over a top-level tree with one mesh instance per leaf (scenes without analytic
+// spheres; those keep the reference-order walk).  A worker is either at the top level (world-space
+// ray, top-level nodes) or inside one instance (object-space ray, that mesh's nodes); its stack
+// holds both kinds of entries, separated by a sentinel that marks the return to the top level.
+// A stolen entry is of the kind its position says: below the victim's sentinel it is a top-level
+// subtree (the thief takes the world ray), above it a subtree of the victim's current instance
+// (the thief takes the victim's object-space ray and instance).  A sentinel at the very bottom
+// of a stack has nothing to return to and is dropped, so the bottom entry can always be given.
+//
+// best[ray] = t bits << 32 | key, key = keyBase[instance] + caller's triangle index with keyBase
+// the running sum of the instances' triangle counts: keys order like (instance, triangle index),
+// so the atomic min implements the result definition of trace_ray() here too.  Scene creation
+// falls back to the per-lane kernel when the keys do not fit 32 bits.
+
+template <bool COUNT>
+struct StealLdsInst : StealLds<COUNT> {
+    uint32_t payInst[64];
+};
+
+__device__ __forceinline__ void hit_barycentrics_inst(const SceneView& sv, uint32_t inst, uint32_t slot, F3 wo, F3 wd, float& beta, float& gamma)
+{
+    const DevInstance& in = sv.inst[inst];
+    const F3 o = xf_point_inv(in.inv, wo), d = xf_vector_inv(in.inv, wd);
+    const float4* tp = tri_ptr(sv, slot);
+    float t;
+    tri_test(tp[0], tp[1], tp[2], o, d, t, beta, gamma);
+}
+
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv, bool hasRay, F3 wo0, F3 wd0, float tmax,
+                                                             StealLdsInst<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
+                                                             const int minIdle = 1, const int leafPct = 48)
+{
+    // rays with a NaN component find nothing (see trace_ray)
+    const bool valid = hasRay && ((wo0.x + wo0.y + wo0.z) + (wd0.x + wd0.y + wd0.z) == (wo0.x + wo0.y + wo0.z) + (wd0.x + wd0.y + wd0.z));
+
+    L.best[lane] = pack_hit(ANY ? tmax : INFINITY, kInvalid);
+    L.paySlot[lane] = kInvalid;
+    L.payInst[lane] = kInvalid;
+    if constexpr (COUNT) { L.cnt[0][lane] = 0; L.cnt[1][lane] = 0; }
+
+    F3 wo = wo0, wd = wd0;                                   // world ray of the ray this worker works for
+    F3 o = wo, d = wd, inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);   // ray of the current level
+    uint32_t nodeBase = sv.topRoot, triBase = 0, curInst = 0, keyBase = 0;
+    bool inMesh = false;
+    int sentPos = -1;          // stack index of the sentinel, -1: none (nothing to return to)
+    int owner = lane;
+    int cur = 0;
+    int sp = 0, sb = 0;
+    bool busy = valid;
+    float tlim = ANY ? tmax : INFINITY;
+    float rtmax = tmax;
+    uint32_t wb = 0, wt = 0;
+    int spill[kStackDepth - kStealStack];
+    const unsigned long long ltMask = (1ull << lane) - 1ull;
+
+    auto push = [&](int v) {
+        if (sp < kStealStack) L.stack[sp][lane] = v;
+        else spill[sp - kStealStack] = v;
+        ++sp;
+    };
+    // Pops the next pending subtree, returning to the top level when the sentinel surfaces; true = nothing left.
+    auto pop = [&]() -> bool {
+        for (;;) {
+            if (sp == sb) return true;
+            --sp;
+            cur = L.stack[sp < kStealStack ? sp : 0][lane];
+            asm volatile("" : "+v"(cur));
+            if (sp >= kStealStack) cur = spill[sp - kStealStack];
+            if (cur != kSentinel) return false;
+            inMesh = false;
+            sentPos = -1;
+            o = wo; d = wd; inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+            nodeBase = sv.topRoot;
+        }
+    };
+
+    for (;;) {
+        const unsigned long long busyMask = wave_ballot(busy);
+        if (busyMask == 0ull) break;
+        const unsigned long long idleMask = ~busyMask;
+        // ---- steal phase -------------------------------------------------------------------------
+        if (__popcll(idleMask) >= minIdle) {
+            if (busy && sentPos >= 0 && sb == sentPos) { ++sb; sentPos = -1; }   // a bottom sentinel has nothing to return to
+            const bool canGive = busy && sb < sp && sb < kStealStack;
+            const unsigned long long giveMask = wave_ballot(canGive);
+            if (giveMask != 0ull) {
+                const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
+                const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
+                if (canGive) L.giveList[rg] = lane;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool thief = !busy && ri < nGive;
+                const int v = L.giveList[thief ? ri : 0];
+                const int vsb = __shfl(sb, v, 64);
+                const int vowner = __shfl(owner, v, 64);
+                const int vsent = __shfl(sentPos, v, 64);
+                const int vinMesh = __shfl((int)inMesh, v, 64);
+                const uint32_t vnodeBase = (uint32_t)__shfl((int)nodeBase, v, 64), vtriBase = (uint32_t)__shfl((int)triBase, v, 64);
+                const uint32_t vcurInst = (uint32_t)__shfl((int)curInst, v, 64), vkeyBase = (uint32_t)__shfl((int)keyBase, v, 64);
+                const float vox = __shfl(o.x, v, 64), voy = __shfl(o.y, v, 64), voz = __shfl(o.z, v, 64);
+                const float vdx = __shfl(d.x, v, 64), vdy = __shfl(d.y, v, 64), vdz = __shfl(d.z, v, 64);
+                const float vix = __shfl(inv.x, v, 64), viy = __shfl(inv.y, v, 64), viz = __shfl(inv.z, v, 64);
+                const float wox = __shfl(wo.x, v, 64), woy = __shfl(wo.y, v, 64), woz = __shfl(wo.z, v, 64);
+                const float wdx = __shfl(wd.x, v, 64), wdy = __shfl(wd.y, v, 64), wdz = __shfl(wd.z, v, 64);
+                const float vtmax = __shfl(rtmax, v, 64);
+                if (thief) {
+                    cur = L.stack[vsb][v];
+                    owner = vowner;
+                    wo = f3(wox, woy, woz); wd = f3(wdx, wdy, wdz);
+                    const bool meshLevel = vinMesh != 0 && (vsent < 0 || vsb > vsent);
+                    if (meshLevel) {
+                        o = f3(vox, voy, voz); d = f3(vdx, vdy, vdz); inv = f3(vix, viy, viz);
+                        nodeBase = vnodeBase; triBase = vtriBase; curInst = vcurInst; keyBase = vkeyBase;
+                        inMesh = true;
+                    } else {
+                        o = wo; d = wd; inv = f3(1.0f / wd.x, 1.0f / wd.y, 1.0f / wd.z);
+                        nodeBase = sv.topRoot;
+                        inMesh = false;
+                    }
+                    sentPos = -1;
+                    rtmax = vtmax;
+                    sp = 0; sb = 0;
+                    busy = true;
+                    tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
+                }
+                if (canGive && rg < nIdle) ++sb;
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        const unsigned long long nowBusy = wave_ballot(busy);
+        const unsigned long long nodeMask = wave_ballot(busy && cur >= 0);
+        const int nBusy = __popcll(nowBusy), nNode = __popcll(nodeMask);
+        const bool nodeStep = nNode > 0 && (nBusy - nNode) * 128 < leafPct * nBusy;
+        bool done = false;
+        if (nodeStep) {
+            // ---- inner node of the top-level tree or of a mesh tree ------------------------------------
+            if (busy && cur >= 0) {
+                const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
+                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
+                if (COUNT) wb += 2;
+                float t0a, t0b;
+                const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
+                const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
+                const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
+                const bool both = ha && hb, any = ha || hb;
+                const bool bFirst = hb && (!ha || t0b < t0a);
+                const int nearC = bFirst ? cb : ca, farC = bFirst ? ca : cb;
+                if (both) push(farC);
+                if (any) cur = nearC;
+                else done = pop();
+            }
+        } else if (busy && cur < 0) {
+            const uint32_t leaf = (uint32_t)(~cur);
+            if (!inMesh) {
+                // ---- top-level leaf: enter the instance (InstancedModelList::traceRay, shape/list/InstancedModelList.cpp:99-138)
+                curInst = sv.instOrder[leaf >> 4];
+                const DevInstance& in = sv.inst[curInst];
+                o = xf_point_inv(in.inv, wo);
+                d = xf_vector_inv(in.inv, wd);
+                inv = f3(1.0f / d.x, 1.0f / d.y, 1.0f / d.z);
+                nodeBase = in.root;
+                triBase = in.triBase;
+                keyBase = in.keyBase;
+                inMesh = true;
+                if (sp > sb) { sentPos = sp; push(kSentinel); }
+                else sentPos = -1;
+                cur = 0;
+            } else {
+                // ---- one triangle of a mesh leaf -------------------------------------------------------
+                const uint32_t slot = triBase + (leaf >> 4);
+                const float4* tp = tri_ptr(sv, slot);
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                float t, be, ga;
+                if (COUNT) wt += 1;
+                if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
+                    if (ANY) {
+                        if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
+                    } else if (t <= tlim) {
+                        const unsigned long long mine = pack_hit(t, keyBase + sv.triIds[slot]);
+                        const unsigned long long old = atomicMin(&L.best[owner], mine);
+                        if (mine < old && L.best[owner] == mine) { L.paySlot[owner] = slot; L.payInst[owner] = curInst; }
+                    }
+                }
+                const unsigned long long b = L.best[owner];
+                tlim = __uint_as_float((uint32_t)(b >> 32));
+                if (ANY && b == 0ull) done = true;
+                else if ((leaf & 15u) != 0u) cur = ~(int)(leaf + 15u);
+                else done = pop();
+            }
+        }
+        if (done) {
+            busy = false;
+            sp = 0; sb = 0;
+            sentPos = -1;
+            if constexpr (COUNT) { atomicAdd(&L.cnt[0][owner], wb); atomicAdd(&L.cnt[1][owner], wt); wb = 0; wt = 0; }
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    TraceResult r;
+    const unsigned long long b = L.best[lane];
+    r.beta = 0.0f; r.gamma = 0.0f;
+    if (ANY) {
+        r.t = tmax; r.slot = kInvalid; r.prim = kInvalid;
+        r.inst = (b == 0ull && valid) ? 0u : kInvalid;
+    } else {
+        r.slot = L.paySlot[lane];
+        const bool hit = r.slot != kInvalid;
+        r.t = hit ? __uint_as_float((uint32_t)(b >> 32)) : INFINITY;
+        r.inst = hit ? L.payInst[lane] : kInvalid;
+        r.prim = hit ? sv.triIds[r.slot] : kInvalid;
+        if (hit) hit_barycentrics_inst(sv, r.inst, r.slot, wo0, wd0, r.beta, r.gamma);
+    }
+    if constexpr (COUNT) { nBoxes = L.cnt[0][lane]; nTris = L.cnt[1][lane]; }
     return r;
 }
 

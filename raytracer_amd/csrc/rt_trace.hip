@@ -110,6 +110,51 @@ __global__ __launch_bounds__(64) void trace_any_steal_kernel(SceneView sv, const
     if (has) occ[i] = r.inst != kInvalid ? 1 : 0;
 }
 
+// Instanced scenes without spheres: the cooperative traversal over top-level and mesh trees.
+template <bool COUNT>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void trace_closest_inst_steal_kernel(SceneView sv, const float* __restrict__ ro,
+                                                                      const float* __restrict__ rd, uint64_t n, uint64_t nb8,
+                                                                      rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
+{
+    __shared__ StealLdsInst<COUNT> lds;
+    const int lane = threadIdx.x;
+    const uint64_t i = interleave8((uint64_t)blockIdx.x * 64 + lane, nb8);
+    const bool has = i < n;
+    const uint64_t j = has ? i : 0;
+    const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
+    const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
+    uint32_t nb = 0, nt = 0;
+    const TraceResult r = trace_wave_steal_inst<false, COUNT>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+    if (!has) return;
+    rtgpu_hit h;
+    h.t = r.t;
+    h.prim = r.prim;
+    h.inst = r.inst;
+    h.beta = r.beta;
+    h.gamma = r.gamma;
+    out[i] = h;
+    if (COUNT) {
+        counts[2 * i] = nb;
+        counts[2 * i + 1] = nt;
+    }
+}
+
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(6))) void trace_any_inst_steal_kernel(SceneView sv, const float* __restrict__ ro,
+                                                                  const float* __restrict__ rd, const float* __restrict__ tmax,
+                                                                  uint64_t n, uint64_t nb8, uint8_t* __restrict__ occ)
+{
+    __shared__ StealLdsInst<false> lds;
+    const int lane = threadIdx.x;
+    const uint64_t i = interleave8((uint64_t)blockIdx.x * 64 + lane, nb8);
+    const bool has = i < n;
+    const uint64_t j = has ? i : 0;
+    const F3 o = f3(ro[3 * j], ro[3 * j + 1], ro[3 * j + 2]);
+    const F3 d = f3(rd[3 * j], rd[3 * j + 1], rd[3 * j + 2]);
+    uint32_t nb = 0, nt = 0;
+    const TraceResult r = trace_wave_steal_inst<true, false>(sv, has, o, d, tmax[j], lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+    if (has) occ[i] = r.inst != kInvalid ? 1 : 0;
+}
+
 template <bool INSTANCED>
 __global__ __launch_bounds__(64) void trace_any_kernel(SceneView sv, const float* __restrict__ ro,
                                                        const float* __restrict__ rd, const float* __restrict__ tmax,
@@ -186,6 +231,10 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
         else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, (size_t)env_int("RTGPU_TRACE_EXTRA_LDS", 0), stream, sv, dO, dD, n, nb8, dHits, dCounts);
         return hipGetLastError();
     }
+    if (sv.coopInstanced && variant != -1 && !dCounts) {
+        hipLaunchKernelGGL((trace_closest_inst_steal_kernel<false>), grid, block, 0, stream, sv, dO, dD, n, interleave_blocks(n), dHits, dCounts);
+        return hipGetLastError();
+    }
     if (sv.singleMesh) {
         if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
         else hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
@@ -205,6 +254,7 @@ hipError_t launch_trace_any(const SceneView& sv, const float* dO, const float* d
     dim3 grid((unsigned)blocks), block(64);
     static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
     if (sv.singleMesh && variant != -1) hipLaunchKernelGGL(trace_any_steal_kernel, grid, block, 0, stream, sv, dO, dD, dTmax, n, interleave_blocks(n), dOcc);
+    else if (sv.coopInstanced && variant != -1) hipLaunchKernelGGL(trace_any_inst_steal_kernel, grid, block, 0, stream, sv, dO, dD, dTmax, n, interleave_blocks(n), dOcc);
     else if (sv.singleMesh) hipLaunchKernelGGL((trace_any_kernel<false>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     else hipLaunchKernelGGL((trace_any_kernel<true>), grid, block, 0, stream, sv, dO, dD, dTmax, n, dOcc);
     return hipGetLastError();

@@ -57,7 +57,7 @@ struct DevInstance {
     uint32_t material;
     float wlo[3], whi[3]; // world AABB (InstancedModelList::getAABB)
     uint32_t meshVertBase; // first vertex-normal triple record of the mesh (shade stage)
-    uint32_t pad;
+    uint32_t keyBase;    // triangles of all instances before this one (tie-break key of the cooperative instanced traversal)
 };
 
 } // namespace rt

@@ -251,7 +251,7 @@ def rel_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / max(float(np.mean(b)), 1e-12))
 
 
-@pytest.mark.parametrize("name,G,M,W,H", [("box", 4, 4, 48, 36), ("box", 16, 16, 32, 24), ("mirror", 4, 16, 40, 30), ("c1", 4, 8, 80, 60),
+@pytest.mark.parametrize("name,G,M,W,H", [("box", 4, 4, 48, 36), ("box", 16, 16, 32, 24), ("mirror", 4, 16, 40, 30), ("c1", 4, 8, 80, 60), ("c1-meshes", 4, 8, 80, 60),
                                           ("coat", 4, 8, 64, 48), ("coat", 9, 4, 40, 30),
                                           ("sun", 4, 4, 64, 48), ("sun+point", 4, 8, 48, 36), ("all", 9, 4, 48, 36)])
 def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
@@ -261,6 +261,8 @@ def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
     may change single pixels, bounded by the RMSE."""
     if name == "c1":
         sc, cam_m, yfov = scenes.c1_scene(n_small=20)
+    elif name == "c1-meshes":  # mesh instances only: the cooperative instanced traversal inside the integrator
+        sc, cam_m, yfov = scenes.c1_scene(n_small=20, with_spheres=False)
     elif name == "coat":  # Fresnel mixes (clear coat), nested mixes and a transparent pane
         sc, cam_m, yfov = scenes.coat_scene()
     elif name in ("sun", "sun+point", "all"):  # directional lights, every combination of light types, environment
