@@ -24,7 +24,7 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
 
 
-def bench_frame(torch, dist, dev, rank, world, frames=3):
+def bench_frame(torch, dist, dev, rank, world, all_reduce, frames=3):
     """ms/frame at fixed spp on configs[2]: the interior scene (~250 k triangles, diffuse + glossy, one
     area and one point light), 1920x1080, 8x8 samples per pixel, path length 9.  The frame is cut into
     interleaved row bands over the ranks (strong scaling) and gathered to rank 0 inside the timed region."""
@@ -49,7 +49,7 @@ def bench_frame(torch, dist, dev, rank, world, frames=3):
         sys.stderr.write("frame pre-flight failed on rank %d: %s\n" % (rank, e))
     if world > 1:
         flag = torch.tensor([ok], dtype=torch.float64, device=dev)
-        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_reduce(flag, dist.ReduceOp.MIN)
         ok = float(flag.item())
     if ok == 0.0:
         scene.close()
@@ -67,10 +67,11 @@ def bench_frame(torch, dist, dev, rank, world, frames=3):
         dt = time.perf_counter() - t0
         r = float(tot["primary_rays"] + tot["extension_rays"] + tot["shadow_rays"])
         if world > 1:
-            tt = torch.tensor([dt, r], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt[0:1], op=dist.ReduceOp.MAX)
-            dist.all_reduce(tt[1:2], op=dist.ReduceOp.SUM)
-            dt, r = float(tt[0].item()), float(tt[1].item())
+            t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
+            r_sum = torch.tensor([r], dtype=torch.float64, device=dev)
+            all_reduce(t_max, dist.ReduceOp.MAX)
+            all_reduce(r_sum, dist.ReduceOp.SUM)
+            dt, r = float(t_max.item()), float(r_sum.item())
         if k > 0:
             times.append(dt)
             rays = r
@@ -103,11 +104,27 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the ray-tracing path)")
+    # RTGPU_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks share
+    # devices, collectives run on host copies); the measured configuration is always nccl = RCCL
+    backend = os.environ.get("RTGPU_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
     api.set_device(local_rank)
+
+    def all_reduce(t, op):
+        if backend == "nccl":
+            dist.all_reduce(t, op=op)
+        else:
+            h = t.cpu()
+            dist.all_reduce(h, op=op)
+            t.copy_(h)
 
     W, H = args.width, args.height
     sc, cam_m, yfov = scenes.blob_scene(args.subdiv)
@@ -156,7 +173,7 @@ def main():
     elapsed = t1 - t0
     if world > 1:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        all_reduce(tt, dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kernel_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
     kernel_ms_avg = float(np.mean(kernel_ms))
@@ -197,7 +214,7 @@ def main():
     }
 
     if not args.no_frame:
-        out["frame"] = bench_frame(torch, dist, dev, rank, world)
+        out["frame"] = bench_frame(torch, dist, dev, rank, world, all_reduce)
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle

@@ -58,6 +58,12 @@ def render_sharded(render_band: Callable, width: int, height: int, rank: int, wo
         r += y1 - y0
     if world == 1:
         gathered = [local]
+    elif local.is_cuda and dist.get_backend(group) == "gloo":
+        # a CPU process group (rehearsals without RCCL): stage the exchange through host memory
+        host = local.cpu()
+        parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
+        dist.gather(host, parts, dst=0, group=group)
+        gathered = [t.to(local.device) for t in parts] if rank == 0 else None
     else:
         gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
         dist.gather(local, gathered, dst=0, group=group)
