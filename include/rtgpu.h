@@ -56,6 +56,8 @@ typedef struct rtgpu_mesh_desc {
     const uint32_t* tri_material; /* n_triangles or NULL */
     uint32_t n_vertices;
     uint32_t n_triangles;
+    const float* texcoords;       /* n_vertices * 2 (TriangleMeshData::texCoords, sharing the vertex indices) or NULL:
+                                   * hits then carry the texture coordinate (0, 0), shape/TriangleMesh.cpp:143-146 */
 } rtgpu_mesh_desc;
 
 /* SceneNode<Model>: transform + (shape, material), scene/renderable/SceneNode.h:5-36,
@@ -83,7 +85,8 @@ typedef struct rtgpu_material {
     float color[3];     /* diffuseColor / color */
     double intensity;   /* diffuseIntensity / emissive intensity */
     float roughness;    /* glossy: roughness; fresnel mix: IOR (FresnelMixMaterial.h: float IOR = 1.45f) */
-    float reserved;
+    uint32_t texture;   /* 1 + index into textures[] of the diffuse albedoMap (material/DiffuseMaterial.cpp:144-152) or the
+                         * emissive emissionMap (material/EmissiveMaterial.cpp:14-21); 0 = none */
     double mix_factor;  /* const mix: 0 = 100 % first, 1 = 100 % second */
     uint32_t first;     /* const / fresnel mix children (material ids) */
     uint32_t second;
@@ -111,6 +114,15 @@ typedef struct rtgpu_directional_light { /* light/DirectionalLight.h:9-24 (world
     double intensity;   /* irradiance */
 } rtgpu_directional_light;
 
+/* TextureUInt8, material/Texture.h:5-61: RGBA8 pixels, rows top to bottom; a lookup takes the texel at
+ * (u * width, v * height) without filtering, divides by 255 and raises to `gamma`. */
+typedef struct rtgpu_texture {
+    const uint8_t* rgba; /* width * height * 4 */
+    uint32_t width;
+    uint32_t height;
+    double gamma;        /* Texture::gamma, 1.0 = none */
+} rtgpu_texture;
+
 typedef struct rtgpu_scene_desc {
     const rtgpu_mesh_desc* meshes;
     const rtgpu_instance_desc* instances;
@@ -127,7 +139,8 @@ typedef struct rtgpu_scene_desc {
     double env_intensity;
     const rtgpu_directional_light* directional_lights; /* may be null when n_directional_lights == 0 */
     uint32_t n_directional_lights;
-    uint32_t reserved;
+    uint32_t n_textures;
+    const rtgpu_texture* textures; /* may be null when n_textures == 0 */
 } rtgpu_scene_desc;
 
 typedef struct rtgpu_scene rtgpu_scene;

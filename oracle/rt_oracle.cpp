@@ -412,6 +412,7 @@ struct Mesh { // TriangleMesh + TriangleMeshData, shape/TriangleMesh.h
     std::vector<V3> vertices, normals;
     std::vector<uint32_t> indices;     // original order, 3 per triangle
     std::vector<uint32_t> triMaterial; // optional
+    std::vector<float> texCoords;      // optional, 2 per vertex (TriangleMeshData::texCoords)
     std::vector<uint32_t> order;       // sorted position -> original triangle (= permutation)
     std::vector<Node> nodes;
     AABB box;                          // TriangleMesh::getAABB(), shape/TriangleMesh.cpp:78-97
@@ -597,6 +598,7 @@ struct SceneHit { // SceneRayHitInfo + RayHitInfo
     uint32_t inst = RTGPU_INVALID_ID;
     uint32_t prim = RTGPU_INVALID_ID; // original triangle index
     float beta = 0, gamma = 0;
+    float u = 0, v = 0;   // RayHitInfo::texCoord
     V3 hitpoint() const { return ro + (rd * (float)t); } // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
 };
 
@@ -611,6 +613,8 @@ struct orc_scene {
     std::vector<rtgpu_point_light> pointLights;
     std::vector<rtgpu_area_light> areaLights;
     std::vector<rtgpu_directional_light> dirLights;
+    struct Tex { std::vector<uint8_t> rgba; uint32_t width, height; double gamma; };
+    std::vector<Tex> textures;
     bool hasEnv = false;
     RGBf envRadiance; // color * intensity, ColorEnvironment.cpp:6-9
 };
@@ -697,6 +701,13 @@ SceneHit scene_trace(const orc_scene& S, V3 o, V3 d)
         float alfa = 1.0f - ih.beta - ih.gamma;
         V3 na = m.normals[m.indices[3 * tri]], nb = m.normals[m.indices[3 * tri + 1]], nc = m.normals[m.indices[3 * tri + 2]];
         objN = ((alfa * na) + (ih.beta * nb)) + (ih.gamma * nc);
+        if (!m.texCoords.empty()) { // shape/TriangleMesh.cpp:122-128; (0, 0) otherwise (:143-146)
+            const float* ta = &m.texCoords[2 * m.indices[3 * tri]];
+            const float* tb = &m.texCoords[2 * m.indices[3 * tri + 1]];
+            const float* tc = &m.texCoords[2 * m.indices[3 * tri + 2]];
+            r.u = ((alfa * ta[0]) + (ih.beta * tb[0])) + (ih.gamma * tc[0]);
+            r.v = ((alfa * ta[1]) + (ih.beta * tb[1])) + (ih.gamma * tc[1]);
+        }
     } else {
         r.prim = RTGPU_INVALID_ID;
         objN = ih.objNormal;
@@ -1193,11 +1204,31 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     }
 }
 
+// Texture::get, material/Texture.h:24-33 (an index equal to the size is clamped; the reference would read past the image)
+RGBf texture_get(const orc_scene::Tex& T, float x, float y)
+{
+    unsigned px = (unsigned)(x * T.width), py = (unsigned)(y * T.height);
+    px = std::min(px, T.width - 1);
+    py = std::min(py, T.height - 1);
+    size_t offset = ((size_t)py * T.width + px) * 4;
+    RGBf color{(float)T.rgba[offset] / 255.0f, (float)T.rgba[offset + 1] / 255.0f, (float)T.rgba[offset + 2] / 255.0f};
+    return RGBf{(float)std::pow(color.r, T.gamma), (float)std::pow(color.g, T.gamma), (float)std::pow(color.b, T.gamma)}; // RGB::pow(double)
+}
+
 // IMaterial::bsdf for the supported closures (leaf material stored by sampleTransport)
 RGBf mat_bsdf(const orc_scene& S, const TransportNode& tn, RGBf incoming)
 {
     const rtgpu_material& m = S.materials[tn.leafMat];
     RGBf color{m.color[0], m.color[1], m.color[2]};
+    if (m.texture != 0 && m.type == RTGPU_MAT_DIFFUSE) { // albedoMap, material/DiffuseMaterial.cpp:144-152
+        float x = fmodf(tn.hit.u, 1.0f), y = fmodf(tn.hit.v, 1.0f);
+        if (x < 0) x = 1.0f + x;
+        if (y < 0) y = 1.0f + y;
+        color = texture_get(S.textures[m.texture - 1], x, y);
+    } else if (m.texture != 0 && m.type == RTGPU_MAT_EMISSIVE) { // emissionMap, material/EmissiveMaterial.cpp:14-21
+        float x = std::abs(std::fmod(tn.hit.u, 1.0f)), y = std::abs(std::fmod(tn.hit.v, 1.0f));
+        color = texture_get(S.textures[m.texture - 1], x, y);
+    }
     switch (m.type) {
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::bsdf, material/DiffuseMaterial.cpp:140-197
         double angle = std::max(0.0f, dot(tn.hit.normal, tn.transportDirection));
@@ -1454,6 +1485,7 @@ orc_scene* orc_scene_create(const rtgpu_scene_desc* desc, int n_threads)
         }
         m.indices.assign(md.indices, md.indices + 3 * (size_t)md.n_triangles);
         if (md.tri_material) m.triMaterial.assign(md.tri_material, md.tri_material + md.n_triangles);
+        if (md.texcoords && desc->n_textures) m.texCoords.assign(md.texcoords, md.texcoords + 2 * (size_t)md.n_vertices);
         mesh_build(m); // InstancedModelList::buildShapeBVHCache, shape/list/InstancedModelList.cpp:60-81
     }
     S->instances.resize(desc->n_instances);
@@ -1480,6 +1512,10 @@ orc_scene* orc_scene_create(const rtgpu_scene_desc* desc, int n_threads)
     S->materials.assign(desc->materials, desc->materials + desc->n_materials);
     S->pointLights.assign(desc->point_lights, desc->point_lights + desc->n_point_lights);
     S->areaLights.assign(desc->area_lights, desc->area_lights + desc->n_area_lights);
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const rtgpu_texture& t = desc->textures[i];
+        S->textures.push_back({std::vector<uint8_t>(t.rgba, t.rgba + (size_t)t.width * t.height * 4), t.width, t.height, t.gamma});
+    }
     if (desc->n_directional_lights) S->dirLights.assign(desc->directional_lights, desc->directional_lights + desc->n_directional_lights);
     S->hasEnv = desc->has_environment != 0;
     S->envRadiance = rgb_scale_d(RGBf{desc->env_color[0], desc->env_color[1], desc->env_color[2]}, desc->env_intensity);

@@ -24,7 +24,8 @@ c_u8_p = C.POINTER(C.c_uint8)
 
 class MeshDesc(C.Structure):
     _fields_ = [("vertices", c_float_p), ("normals", c_float_p), ("indices", c_u32_p),
-                ("tri_material", c_u32_p), ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32)]
+                ("tri_material", c_u32_p), ("n_vertices", C.c_uint32), ("n_triangles", C.c_uint32),
+                ("texcoords", c_float_p)]
 
 
 class InstanceDesc(C.Structure):
@@ -34,7 +35,7 @@ class InstanceDesc(C.Structure):
 
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_double),
-                ("roughness", C.c_float), ("reserved", C.c_float), ("mix_factor", C.c_double),
+                ("roughness", C.c_float), ("texture", C.c_uint32), ("mix_factor", C.c_double),
                 ("first", C.c_uint32), ("second", C.c_uint32)]
 
 
@@ -52,6 +53,10 @@ class DirectionalLight(C.Structure):
                 ("intensity", C.c_double)]
 
 
+class Texture(C.Structure):
+    _fields_ = [("rgba", c_u8_p), ("width", C.c_uint32), ("height", C.c_uint32), ("gamma", C.c_double)]
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("instances", C.POINTER(InstanceDesc)),
                 ("materials", C.POINTER(Material)), ("point_lights", C.POINTER(PointLight)),
@@ -60,7 +65,7 @@ class SceneDesc(C.Structure):
                 ("n_point_lights", C.c_uint32), ("n_area_lights", C.c_uint32),
                 ("has_environment", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_double),
                 ("directional_lights", C.POINTER(DirectionalLight)), ("n_directional_lights", C.c_uint32),
-                ("reserved", C.c_uint32)]
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture))]
 
 
 class Hit(C.Structure):
@@ -108,6 +113,7 @@ class MeshData:
     normals: np.ndarray                      # (nv, 3) float32
     indices: np.ndarray                      # (nt, 3) uint32
     tri_material: Optional[np.ndarray] = None  # (nt,) uint32
+    texcoords: Optional[np.ndarray] = None     # (nv, 2) float32
 
 
 @dataclass
@@ -127,6 +133,7 @@ class MaterialData:
     mix_factor: float = 0.0
     first: int = 0
     second: int = 0
+    texture: Optional[int] = None   # index into SceneData.textures (albedo of a diffuse, emission of an emissive material)
 
 
 @dataclass
@@ -137,6 +144,7 @@ class SceneData:
     point_lights: List[tuple] = field(default_factory=list)   # (pos3, color3, intensity)
     area_lights: List[tuple] = field(default_factory=list)    # (a3, b3, c3, color3, intensity)
     directional_lights: List[tuple] = field(default_factory=list)  # (direction3, angle, color3, intensity)
+    textures: List[tuple] = field(default_factory=list)       # ((h, w, 4) uint8 pixels, gamma)
     env: Optional[tuple] = None                               # (color3, intensity)
 
     def n_triangles(self) -> int:
@@ -168,6 +176,12 @@ class PackedScene:
                     raise ValueError("tri_material must have one entry per triangle")
                 self._keep.append(tm)
                 meshes[i].tri_material = tm.ctypes.data_as(c_u32_p)
+            if m.texcoords is not None:
+                uv = np.ascontiguousarray(m.texcoords, dtype=np.float32).reshape(-1, 2)
+                if uv.shape[0] != v.shape[0]:
+                    raise ValueError("texcoords must be per vertex")
+                self._keep.append(uv)
+                meshes[i].texcoords = uv.ctypes.data_as(c_float_p)
             meshes[i].n_vertices = v.shape[0]
             meshes[i].n_triangles = idx.shape[0]
         n_inst = len(scene.instances)
@@ -189,6 +203,7 @@ class PackedScene:
             mats[i].mix_factor = float(m.mix_factor)
             mats[i].first = int(m.first)
             mats[i].second = int(m.second)
+            mats[i].texture = 0 if m.texture is None else int(m.texture) + 1
         n_pl = len(scene.point_lights)
         pls = (PointLight * max(1, n_pl))()
         for i, (pos, col, inten) in enumerate(scene.point_lights):
@@ -221,6 +236,19 @@ class PackedScene:
         d.n_point_lights, d.n_area_lights = n_pl, n_al
         d.directional_lights = dls
         d.n_directional_lights = n_dl
+        n_tx = len(scene.textures)
+        txs = (Texture * max(1, n_tx))()
+        for i, (pixels, gamma) in enumerate(scene.textures):
+            px = np.ascontiguousarray(pixels, dtype=np.uint8)
+            if px.ndim != 3 or px.shape[2] != 4:
+                raise ValueError("texture pixels must have shape (height, width, 4)")
+            self._keep.append(px)
+            txs[i].rgba = px.ctypes.data_as(c_u8_p)
+            txs[i].height, txs[i].width = px.shape[0], px.shape[1]
+            txs[i].gamma = float(gamma)
+        self._keep.append(txs)
+        d.textures = txs
+        d.n_textures = n_tx
         if scene.env is not None:
             d.has_environment = 1
             d.env_color[:] = [float(x) for x in scene.env[0]]

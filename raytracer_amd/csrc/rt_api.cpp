@@ -111,9 +111,17 @@ int validate(const rtgpu_scene_desc* d)
         if (!affine(id.transform) || !affine(id.inverse))
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance transforms must be affine (last row 0 0 0 1)");
     }
+    if (d->n_textures && !d->textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null texture array");
+    for (uint32_t i = 0; i < d->n_textures; ++i) {
+        const rtgpu_texture& t = d->textures[i];
+        // Texture's constructor checks the buffer size (material/Texture.h:18-21); an empty image cannot be sampled
+        if (!t.rgba || t.width == 0 || t.height == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "texture without pixels");
+        if ((uint64_t)t.width * t.height >= (1ull << 30)) return fail(RTGPU_ERR_LIMIT, "texture larger than 2^30 pixels");
+    }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rtgpu_material& m = d->materials[i];
         if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_TRANSPARENT) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
+        if (m.texture > d->n_textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
         auto is_mix = [&](uint32_t k) { return d->materials[k].type == RTGPU_MAT_CONSTMIX || d->materials[k].type == RTGPU_MAT_FRESNELMIX; };
         if (is_mix(i)) {
             if (m.first >= d->n_materials || m.second >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix material child out of range");
@@ -142,7 +150,7 @@ void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
-                          view.materials, view.pointLights, view.areaLights, view.dirLights};
+                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
     view = rt::SceneView{};
@@ -291,9 +299,13 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     std::vector<float> vertNormals;
     std::vector<uint32_t> meshRoot(desc->n_meshes), meshTriBase(desc->n_meshes);
     rtgpu_scene_info info{};
-    bool anyTriMat = false;
-    for (uint32_t m = 0; m < desc->n_meshes; ++m)
+    bool anyTriMat = false, anyUV = false;
+    for (uint32_t m = 0; m < desc->n_meshes; ++m) {
         if (desc->meshes[m].tri_material) anyTriMat = true;
+        if (desc->meshes[m].texcoords) anyUV = true;
+    }
+    if (desc->n_textures == 0) anyUV = false;   // texture coordinates are only read by texture lookups
+    std::vector<float> vertUV;
     for (uint32_t m = 0; m < desc->n_meshes; ++m) {
         const rtgpu_mesh_desc& md = desc->meshes[m];
         BuildParams bp;
@@ -314,6 +326,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         triIds.resize(base + md.n_triangles);
         vertNormals.resize((base + md.n_triangles) * 9);
         if (anyTriMat) triMat.resize(base + md.n_triangles);
+        if (anyUV) vertUV.resize((base + md.n_triangles) * 6, 0.0f);
         parallel_for(md.n_triangles, threads, [&](size_t b, size_t e) {
             for (size_t s = b; s < e; ++s) {
                 const uint32_t tri = bt.order[s];
@@ -336,6 +349,12 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
                 std::memcpy(vn + 3, md.normals + 3 * (size_t)i1, 12);
                 std::memcpy(vn + 6, md.normals + 3 * (size_t)i2, 12);
                 if (anyTriMat) triMat[base + s] = md.tri_material ? md.tri_material[tri] : kInvalid;
+                if (anyUV && md.texcoords) {
+                    float* uv = vertUV.data() + (base + s) * 6;
+                    std::memcpy(uv, md.texcoords + 2 * (size_t)i0, 8);
+                    std::memcpy(uv + 2, md.texcoords + 2 * (size_t)i1, 8);
+                    std::memcpy(uv + 4, md.texcoords + 2 * (size_t)i2, 8);
+                }
             }
         });
         info.n_triangles += md.n_triangles;
@@ -387,6 +406,21 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         dm.first = m.first;
         dm.second = m.second;
         dm.intensity = m.intensity;
+        dm.texture = m.texture;
+        dm.pad = 0;
+    }
+    std::vector<DevTexture> texs(desc->n_textures);
+    std::vector<uint32_t> texels;
+    for (uint32_t i = 0; i < desc->n_textures; ++i) {
+        const rtgpu_texture& t = desc->textures[i];
+        texs[i].offset = (uint32_t)texels.size();
+        texs[i].width = t.width;
+        texs[i].height = t.height;
+        texs[i].gamma = t.gamma;
+        const size_t n = (size_t)t.width * t.height;
+        if (texels.size() + n >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "textures exceed 2^32 texels");
+        texels.resize(texels.size() + n);
+        std::memcpy(texels.data() + texs[i].offset, t.rgba, n * 4);
     }
     std::vector<DevPointLight> pls(desc->n_point_lights);
     for (uint32_t i = 0; i < desc->n_point_lights; ++i) {
@@ -434,7 +468,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     if ((rc = upload(triIds, &v.triIds, bytes)) || (rc = upload(inst, &v.inst, bytes)) || (rc = upload(instOrder, &v.instOrder, bytes)) ||
         (rc = upload(vertNormals, &v.vertNormals, bytes)) || (rc = upload(triMat, &v.triMaterial, bytes)) ||
         (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
-        (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes))) {
+        (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes)) ||
+        (rc = upload(vertUV, &v.vertUV, bytes)) || (rc = upload(texs, &v.textures, bytes)) || (rc = upload(texels, &v.texels, bytes))) {
         sc->release();
         delete sc;
         return rc;

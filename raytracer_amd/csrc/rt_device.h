@@ -15,6 +15,15 @@ struct DevMaterial {
     float mixFactor;
     uint32_t first, second;
     double intensity;
+    uint32_t texture;   // 1 + texture index (albedo / emission map), 0 = none
+    uint32_t pad;
+};
+
+struct DevTexture {
+    uint32_t offset;    // first texel in SceneView::texels
+    uint32_t width, height;
+    uint32_t pad;
+    double gamma;
 };
 
 struct DevPointLight {
@@ -62,6 +71,9 @@ struct SceneView {
     const DevPointLight* pointLights;
     const DevAreaLight* areaLights;
     const DevDirectionalLight* dirLights;
+    const float* vertUV;        // per leaf slot: 3 texture coordinates (6 floats), null when no texture is used
+    const DevTexture* textures;
+    const uint32_t* texels;     // RGBA8 texels of all textures
     uint32_t nMaterials, nPointLights, nAreaLights, nDirLights;
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal

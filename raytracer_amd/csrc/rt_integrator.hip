@@ -385,7 +385,12 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 mi = choseFirst ? mm.first : mm.second;
             }
             const DevMaterial& mat = sv.materials[mi];
-            const RGBf color = rgb(mat.color[0], mat.color[1], mat.color[2]);
+            RGBf color = rgb(mat.color[0], mat.color[1], mat.color[2]);
+            if (mat.texture != 0u && (mat.type == RTGPU_MAT_DIFFUSE || mat.type == RTGPU_MAT_EMISSIVE)) {
+                float tu, tv;
+                hit_texcoord(sv, slot, beta, gamma, tu, tv);
+                color = mat.type == RTGPU_MAT_DIFFUSE ? albedo_lookup(sv, mat.texture - 1u, tu, tv) : emission_lookup(sv, mat.texture - 1u, tu, tv);
+            }
             const F3 hitpoint = o + (d * t); // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
             const bool lastVertex = (k + 1 == maxLen); // such a path is "terminated" and contributes nothing
 

@@ -246,6 +246,45 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
     return out;
 }
 
+// RayHitInfo::texCoord of a triangle hit: (alfa * aTexCoord) + (beta * bTexCoord) + (gamma * cTexCoord),
+// shape/TriangleMesh.cpp:122-128; (0, 0) for meshes without texture coordinates (:143-146) and, as a
+// definition, for spheres (the reference leaves it uninitialised there, shape/Sphere.cpp:55-58).
+__device__ __forceinline__ void hit_texcoord(const SceneView& sv, uint32_t slot, float beta, float gamma, float& u, float& v)
+{
+    u = 0.0f; v = 0.0f;
+    if (slot == kInvalid || !sv.vertUV) return;
+    const float* t = sv.vertUV + (size_t)slot * 6;
+    const float alfa = 1.0f - beta - gamma;
+    u = ((alfa * t[0]) + (beta * t[2])) + (gamma * t[4]);
+    v = ((alfa * t[1]) + (beta * t[3])) + (gamma * t[5]);
+}
+
+// Texture::get(x * width, y * height), material/Texture.h:24-33: the texel without filtering, / 255, ^gamma.
+// (An index that rounds up to the image size would read past the image in the reference; it is clamped.)
+__device__ __forceinline__ RGBf texture_get(const SceneView& sv, uint32_t texture, float x, float y)
+{
+    const DevTexture& T = sv.textures[texture];
+    uint32_t px = (uint32_t)(x * T.width), py = (uint32_t)(y * T.height);
+    if (px > T.width - 1) px = T.width - 1;
+    if (py > T.height - 1) py = T.height - 1;
+    const uint32_t texel = sv.texels[T.offset + py * T.width + px];
+    const float r = (float)(texel & 255u) / 255.0f, g = (float)((texel >> 8) & 255u) / 255.0f, b = (float)((texel >> 16) & 255u) / 255.0f;
+    return rgb((float)pow((double)r, T.gamma), (float)pow((double)g, T.gamma), (float)pow((double)b, T.gamma));
+}
+// diffuseColor of DiffuseMaterial::bsdf with an albedoMap, material/DiffuseMaterial.cpp:144-152
+__device__ __forceinline__ RGBf albedo_lookup(const SceneView& sv, uint32_t texture, float u, float v)
+{
+    float x = fmodf(u, 1.0f), y = fmodf(v, 1.0f);
+    if (x < 0) x = 1.0f + x;
+    if (y < 0) y = 1.0f + y;
+    return texture_get(sv, texture, x, y);
+}
+// emissionColor of EmissiveMaterial::bsdf with an emissionMap, material/EmissiveMaterial.cpp:14-21
+__device__ __forceinline__ RGBf emission_lookup(const SceneView& sv, uint32_t texture, float u, float v)
+{
+    return texture_get(sv, texture, fabsf(fmodf(u, 1.0f)), fabsf(fmodf(v, 1.0f)));
+}
+
 // FresnelMixMaterial::calcMixFactor, material/FresnelMixMaterial.cpp:3-41: unpolarised Fresnel
 // reflectance of the hit for index of refraction `ior` against air, 1 on total internal reflection.
 __device__ __forceinline__ float fresnel_mix_factor(F3 normal, F3 incomingDir, float ior)

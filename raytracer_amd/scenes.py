@@ -437,6 +437,41 @@ def sun_scene(lights="sun+point"):
     return sc, cam_m, 0.8
 
 
+def textured_scene(seed=3):
+    """The box of box_scene with an albedo map on the floor and the back wall (texture coordinates beyond
+    [0, 1) and negative ones included), a gamma-corrected map on one sphere and an emission map on a small panel."""
+    rng = np.random.RandomState(seed)
+    sc, cam_m, yfov = box_scene()
+    mesh = sc.meshes[0]
+    v = mesh.vertices
+    uv = np.stack([v[:, 0] * 0.55 - 0.3 + 0.35 * v[:, 1], v[:, 2] * 0.6 - 0.4 + 0.2 * v[:, 1]], axis=1).astype(np.float32)
+    panel_v, panel_f = grid_quad((1.2, 2.2, 0.05), (1.6, 0.0, 0.0), (0.0, 1.0, 0.0), 2, 2)
+    panel_v = np.asarray(panel_v, dtype=np.float32)
+    panel_f = np.asarray(panel_f, dtype=np.uint32)
+    panel_uv = np.stack([(panel_v[:, 0] - 1.2) / 1.6, (panel_v[:, 1] - 2.2) / 1.0], axis=1).astype(np.float32)
+    base = len(sc.materials)
+    checker = rng.randint(40, 256, size=(8, 8, 4)).astype(np.uint8)
+    stripes = np.zeros((4, 16, 4), np.uint8)
+    stripes[:, ::2] = (250, 220, 90, 255)
+    stripes[:, 1::2] = (40, 60, 200, 255)
+    glow = rng.randint(0, 256, size=(3, 5, 4)).astype(np.uint8)
+    sc.textures = [(checker, 1.0), (stripes, 2.2), (glow, 1.0)]
+    sc.materials += [MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=0), MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=1),
+                     MaterialData(MAT_EMISSIVE, (1.0, 1.0, 1.0), intensity=1.5, texture=2)]
+    tm = mesh.tri_material.copy()
+    quad = 2 * 6 * 6
+    tm[0:quad] = base            # floor
+    tm[2 * quad:3 * quad] = base  # back wall
+    nsph = (len(tm) - 6 * quad) // 2
+    tm[6 * quad + nsph:] = base + 1   # second sphere
+    nv = len(mesh.vertices)
+    sc.meshes = [MeshData(np.concatenate([mesh.vertices, panel_v]), np.concatenate([mesh.normals, vertex_normals(panel_v, panel_f)]),
+                          np.concatenate([mesh.indices, panel_f + np.uint32(nv)]),
+                          np.concatenate([tm, np.full(len(panel_f), base + 2, dtype=np.uint32)]),
+                          np.concatenate([uv, panel_uv]))]
+    return sc, cam_m, yfov
+
+
 def random_rays(n, lo, hi, seed=0):
     """Incoherent rays: origins uniform in the box [lo,hi], directions uniform on the sphere."""
     rng = np.random.RandomState(seed)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layouts_match_the_header():
     structs = {"rtgpu_mesh_desc": abi.MeshDesc, "rtgpu_instance_desc": abi.InstanceDesc, "rtgpu_material": abi.Material,
                "rtgpu_point_light": abi.PointLight, "rtgpu_area_light": abi.AreaLight,
-               "rtgpu_directional_light": abi.DirectionalLight, "rtgpu_scene_desc": abi.SceneDesc,
+               "rtgpu_directional_light": abi.DirectionalLight, "rtgpu_texture": abi.Texture, "rtgpu_scene_desc": abi.SceneDesc,
                "rtgpu_hit": abi.Hit, "rtgpu_camera": abi.Camera, "rtgpu_render_settings": abi.RenderSettings,
                "rtgpu_render_stats": abi.RenderStats, "rtgpu_scene_info": abi.SceneInfo}
     src = '#include <stdio.h>\n#include "rtgpu.h"\nint main(void){\n'
