@@ -77,7 +77,12 @@ typedef enum rtgpu_material_type {
     RTGPU_MAT_CONSTMIX = 3, /* material/MixMaterial.h:19-26 */
     RTGPU_MAT_FRESNELMIX = 4,  /* material/FresnelMixMaterial.cpp:3-41: mix whose factor is the Fresnel reflectance
                                 * of the hit (clear coat); `roughness` carries the index of refraction */
-    RTGPU_MAT_TRANSPARENT = 5  /* material/TransparentMaterial.cpp:3-26: the path goes straight on */
+    RTGPU_MAT_TRANSPARENT = 5, /* material/TransparentMaterial.cpp:3-26: the path goes straight on */
+    RTGPU_MAT_GLASS = 6,    /* material/GlassMaterial.cpp:21-178 (GlassMaterial.h:15-17): `intensity` = ior (double there),
+                             * `roughness` = attenuationStrength (float there), `color` = the absorption colour.
+                             * At most two mix levels above it (the reference's metadata tree, utility/DynAllocTree.h) */
+    RTGPU_MAT_ADD = 7       /* material/AddMaterial.cpp:5-17: `first` (an emissive material, as io/GLTF.cpp:435-441
+                             * builds it) is added to what `second` returns for the same path vertex */
 } rtgpu_material_type;
 
 typedef struct rtgpu_material {
@@ -88,7 +93,7 @@ typedef struct rtgpu_material {
     uint32_t texture;   /* 1 + index into textures[] of the diffuse albedoMap (material/DiffuseMaterial.cpp:144-152) or the
                          * emissive emissionMap (material/EmissiveMaterial.cpp:14-21); 0 = none */
     double mix_factor;  /* const mix: 0 = 100 % first, 1 = 100 % second */
-    uint32_t first;     /* const / fresnel mix children (material ids) */
+    uint32_t first;     /* children of a const / fresnel mix or of an add material (material ids) */
     uint32_t second;
 } rtgpu_material;
 

@@ -742,7 +742,7 @@ inline float rand_unit(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t 
 
 enum Dim : uint32_t {
     DIM_NEE_CHOICE = 1, DIM_LIGHT_TYPE = 2, DIM_LIGHT_INDEX = 3, DIM_AREA_U = 4, DIM_AREA_V = 5,
-    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_MIX0 = 12
+    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_GLASS = 11, DIM_MIX0 = 12
 };
 constexpr uint32_t VERTEX_CAMERA = 255;
 
@@ -1014,6 +1014,20 @@ struct TransportNode { // material/IMaterial.h:17-30 + the per-material Transpor
     RGBf directLighting;       // DiffuseMaterial
     RGBf neeRadiance;          // GlossyMaterial
     int lightHit = -1;         // GlossyMaterial, index into areaLights
+    // GlassMaterial's TransportMetaData (material/GlassMaterial.cpp:11-18).  The reference keeps metadata in
+    // a tree with one slot per MixMaterial branch (utility/DynAllocTree.h:118-131: depth 3, two children),
+    // and a slot survives every re-sampling pass of the node (renderer/Renderer.cpp:246 keeps the node).
+    struct GlassMeta {
+        bool used = false;
+        float reflectionWeight = 0, t = 0;
+        V3 reflectedRayDir{}, transmittedRayDir{};
+        int lightHit = -1;
+    };
+    GlassMeta glass[7];
+    int leafSlot = 0;          // metadata slot of the leaf material chosen in the current pass
+    // AddMaterial (material/AddMaterial.cpp:5-17): the emissive first children met on the way to the leaf
+    uint32_t addFirst[4] = {0, 0, 0, 0};
+    int nAdd = 0;
 };
 
 uint32_t hit_material(const orc_scene& S, const SceneHit& h) // Model material / CompositeMaterial::findMaterial
@@ -1066,6 +1080,8 @@ bool mat_has_variance(const orc_scene& S, uint32_t mi, const SceneHit& h)
     case RTGPU_MAT_GLOSSY: return m.roughness > 0.0f;
     case RTGPU_MAT_EMISSIVE: return false;
     case RTGPU_MAT_TRANSPARENT: return false;
+    case RTGPU_MAT_GLASS: return true;  // GlassMaterial.cpp:254-257
+    case RTGPU_MAT_ADD: return mat_has_variance(S, m.first, h) || mat_has_variance(S, m.second, h); // AddMaterial.cpp:25-28
     case RTGPU_MAT_CONSTMIX:
     case RTGPU_MAT_FRESNELMIX: {
         float mf = mat_mix_factor(m, h);
@@ -1079,6 +1095,7 @@ bool mat_has_variance(const orc_scene& S, uint32_t mi, const SceneHit& h)
 struct SampleOut {
     bool hasNextHit = false;
     SceneHit nextHit;
+    bool tracedMiss = false;   // the material traced the ray samplePath would trace (same origin) and it left the scene
 };
 
 // Triangle::intersect against every area light (renderer/Renderer.cpp:184-204, GlossyMaterial.cpp:126-178)
@@ -1089,15 +1106,93 @@ inline bool area_light_hit(const rtgpu_area_light& L, V3 o, V3 d, double& t)
 }
 
 // IMaterial::sampleTransport for the supported closures
-void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI, int sampleCount, const RandCtx& rc, int mixLevel, SampleOut& out)
+void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI, int sampleCount, const RandCtx& rc, int mixLevel, SampleOut& out,
+                      int metaIndex = 0, int levelsDeep = 0)
 {
     const orc_scene& S = R.S;
     const rtgpu_material& m = S.materials[mi];
+    if (mixLevel == 0) tn.nAdd = 0;
     switch (m.type) {
     case RTGPU_MAT_CONSTMIX:
     case RTGPU_MAT_FRESNELMIX: { // MixMaterial::sampleTransport, material/MixMaterial.cpp:9-26
         bool choseFirst = rc.unit(DIM_MIX0 + mixLevel) > mat_mix_factor(m, tn.hit);
-        sample_transport(R, tn, choseFirst ? m.first : m.second, sampleI, sampleCount, rc, mixLevel + 1, out);
+        // DynAllocTree::branch(choseFirst), utility/DynAllocTree.h:118-131
+        int deeper = levelsDeep + 1;
+        int childSize = (1 << (3 - deeper)) - 1;
+        int childIndex = metaIndex + 1 + ((choseFirst ? 1 : 0) * childSize);
+        sample_transport(R, tn, choseFirst ? m.first : m.second, sampleI, sampleCount, rc, mixLevel + 1, out, childIndex, deeper);
+        return;
+    }
+    case RTGPU_MAT_ADD: { // AddMaterial::sampleTransport, material/AddMaterial.cpp:5-10: both children sample the same node, the second last
+        if (tn.nAdd >= 4) { std::fprintf(stderr, "oracle: AddMaterial nested more than 4 deep\n"); std::abort(); }
+        tn.addFirst[tn.nAdd++] = m.first;
+        sample_transport(R, tn, m.second, sampleI, sampleCount, rc, mixLevel + 1, out, metaIndex, levelsDeep);
+        return;
+    }
+    case RTGPU_MAT_GLASS: { // GlassMaterial::sampleTransport, material/GlassMaterial.cpp:21-133 (no photon map)
+        if (metaIndex >= 7) { std::fprintf(stderr, "oracle: GlassMaterial below more than two MixMaterial levels\n"); std::abort(); }
+        tn.leafMat = mi;
+        tn.leafSlot = metaIndex;
+        tn.isNEERay = false;
+        TransportNode::GlassMeta& meta = tn.glass[metaIndex];
+        if (!meta.used) {
+            meta = TransportNode::GlassMeta{};
+            meta.used = true;
+            tn.isEmissive = false;
+            tn.pathTerminationChance = 0.1f;
+            V3& normal = tn.hit.normal;   // the reference flips the node's normal in place (:45, :77)
+            V3 incomingDir = tn.hit.rd;
+            V3 objToIncoming = -incomingDir;
+            meta.reflectedRayDir = (-objToIncoming) + ((float)(2.0 * dot(normal, objToIncoming)) * normal);
+            double nDotWo = dot(normal, objToIncoming);
+            double incomingAngle = nDotWo;
+            bool isInternalRay = nDotWo < 0;
+            double curRelIor = m.intensity / 1.0;
+            if (isInternalRay) curRelIor = 1.0 / curRelIor;
+            double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+            bool tir = cosTransmissionSqr < 0;
+            if (tir) {
+                meta.reflectionWeight = 1.0;
+                meta.t = NAN;
+                tn.transportDirection = meta.reflectedRayDir;
+                return;
+            }
+            if (isInternalRay) {
+                nDotWo = -nDotWo;
+                incomingAngle = -incomingAngle;
+                normal = -normal;
+            }
+            double cosRefractAngle = std::sqrt(cosTransmissionSqr);
+            meta.transmittedRayDir = (incomingDir / (float)curRelIor) - ((float)(cosRefractAngle - (incomingAngle / curRelIor)) * normal);
+            double rs = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+            double rp = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+            double kr = ((rs * rs) + (rp * rp)) / 2.0;
+            double reflectionWeight = kr;
+            double transmissionWeight = 1.0 - kr;
+            double totalWeight = reflectionWeight + transmissionWeight;
+            meta.reflectionWeight = (float)(reflectionWeight / totalWeight);
+        }
+        tn.transportDirection = rc.unit(DIM_GLASS) < meta.reflectionWeight ? meta.reflectedRayDir : meta.transmittedRayDir;
+        V3 hitpoint = tn.hit.hitpoint();
+        V3 ro = hitpoint + (tn.transportDirection * 0.0001f);
+        R.extension++;
+        SceneHit result = scene_trace(S, ro, tn.transportDirection);
+        double bestT = result.ok ? result.t : 1E99;
+        for (size_t li = 0; li < S.areaLights.size(); ++li) {
+            double lt;
+            if (area_light_hit(S.areaLights[li], ro, tn.transportDirection, lt) && bestT > lt) { meta.lightHit = (int)li; bestT = lt; }
+        }
+        meta.t = (float)bestT;
+        if (meta.lightHit < 0) {   // also a light found by an earlier pass of this node keeps it emissive
+            out.hasNextHit = result.ok;
+            out.nextHit = result;
+            out.tracedMiss = !result.ok;
+            tn.isEmissive = false;
+            tn.pathTerminationChance = 0.1f;
+        } else {
+            tn.isEmissive = true;
+            tn.pathTerminationChance = 1.0f;
+        }
         return;
     }
     case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::sampleTransport, material/TransparentMaterial.cpp:3-11
@@ -1215,10 +1310,10 @@ RGBf texture_get(const orc_scene::Tex& T, float x, float y)
     return RGBf{(float)std::pow(color.r, T.gamma), (float)std::pow(color.g, T.gamma), (float)std::pow(color.b, T.gamma)}; // RGB::pow(double)
 }
 
-// IMaterial::bsdf for the supported closures (leaf material stored by sampleTransport)
-RGBf mat_bsdf(const orc_scene& S, const TransportNode& tn, RGBf incoming)
+// IMaterial::bsdf for the supported closures
+RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf incoming)
 {
-    const rtgpu_material& m = S.materials[tn.leafMat];
+    const rtgpu_material& m = S.materials[mi];
     RGBf color{m.color[0], m.color[1], m.color[2]};
     if (m.texture != 0 && m.type == RTGPU_MAT_DIFFUSE) { // albedoMap, material/DiffuseMaterial.cpp:144-152
         float x = fmodf(tn.hit.u, 1.0f), y = fmodf(tn.hit.v, 1.0f);
@@ -1260,8 +1355,43 @@ RGBf mat_bsdf(const orc_scene& S, const TransportNode& tn, RGBf incoming)
         return rgb_scale_d(color, m.intensity);
     case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::bsdf, material/TransparentMaterial.cpp:13-16
         return incoming;
+    case RTGPU_MAT_GLASS: { // GlassMaterial::bsdf, material/GlassMaterial.cpp:135-178
+        const TransportNode::GlassMeta& meta = tn.glass[tn.leafSlot];
+        V3 normal = tn.hit.normal;
+        V3 direction = tn.transportDirection;
+        bool isInternalRay = dot(normal, direction) < 0;
+        RGBf val = incoming;
+        if (meta.lightHit >= 0) {
+            const rtgpu_area_light& L = S.areaLights[meta.lightHit];
+            RGBf lightEnergy = light_energy(L.color, L.intensity);
+            RGBf lightIrradiance = rgb_div_d(lightEnergy, (double)tri_area(mk(L.a), mk(L.b), mk(L.c)));
+            RGBf lightRadiance = rgb_div_d(lightIrradiance, PI);
+            V3 lampPoint = tn.transportDirection * meta.t;   // as the reference has it: not offset by the hit point
+            V3 objectToLamp = normalized(lampPoint - tn.hit.hitpoint());
+            float angle = std::max(0.0f, dot(normal, objectToLamp));
+            val = rgb_scale_d(lightRadiance, (double)angle);
+        }
+        if (isInternalRay) {
+            double t = std::isnan(meta.t) ? tn.hit.t : (double)meta.t;
+            double power = m.roughness * t;   // attenuationStrength (float) * t
+            val = rgb_mul(val, RGBf{(float)std::pow(m.color[0], power), (float)std::pow(m.color[1], power), (float)std::pow(m.color[2], power)});
+        }
+        return val;
+    }
     default: return RGBf{};
     }
+}
+
+// The node's material evaluated the way sampleTransport walked it: the leaf, plus the emissive first child of
+// every AddMaterial above it (AddMaterial::bsdf, material/AddMaterial.cpp:12-17: result1 + result2)
+RGBf mat_bsdf(const orc_scene& S, const TransportNode& tn, RGBf incoming)
+{
+    RGBf r = leaf_bsdf(S, tn, tn.leafMat, incoming);
+    for (int a = tn.nAdd - 1; a >= 0; --a) {
+        RGBf e = leaf_bsdf(S, tn, tn.addFirst[a], incoming);
+        r = RGBf{e.r + r.r, e.g + r.g, e.b + r.b};
+    }
+    return r;
 }
 
 struct PathKey {
@@ -1293,6 +1423,7 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
         if (!pathDone) {
             SceneHit hit;
             if (so.hasNextHit) hit = so.nextHit;
+            else if (so.tracedMiss) hit = SceneHit{};   // GlassMaterial traced this very ray (offset 1e-4): the repeat of Renderer.cpp:57-61 misses again
             else {
                 // renderer/Renderer.cpp:57-61; also reached when GlossyMaterial's own trace (1e-3
                 // offset) found nothing: ctx.nextHit is empty, so the reference traces again

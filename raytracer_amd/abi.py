@@ -14,7 +14,7 @@ import numpy as np
 INVALID_ID = 0xFFFFFFFF
 SHAPE_SPHERE = -1
 
-MAT_DIFFUSE, MAT_GLOSSY, MAT_EMISSIVE, MAT_CONSTMIX, MAT_FRESNELMIX, MAT_TRANSPARENT = 0, 1, 2, 3, 4, 5
+MAT_DIFFUSE, MAT_GLOSSY, MAT_EMISSIVE, MAT_CONSTMIX, MAT_FRESNELMIX, MAT_TRANSPARENT, MAT_GLASS, MAT_ADD = 0, 1, 2, 3, 4, 5, 6, 7
 JITTER_RANDOM, JITTER_CENTER = 0, 1
 
 c_float_p = C.POINTER(C.c_float)

@@ -120,21 +120,69 @@ int validate(const rtgpu_scene_desc* d)
     }
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rtgpu_material& m = d->materials[i];
-        if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_TRANSPARENT) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
+        if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_ADD) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
         if (m.texture > d->n_textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
-        auto is_mix = [&](uint32_t k) { return d->materials[k].type == RTGPU_MAT_CONSTMIX || d->materials[k].type == RTGPU_MAT_FRESNELMIX; };
-        if (is_mix(i)) {
-            if (m.first >= d->n_materials || m.second >= d->n_materials) return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix material child out of range");
-            // nested mixes are resolved at most kMaxMixDepth deep on the device
-            uint32_t depth = 0, cur = i;
-            while (is_mix(cur) && depth <= 4) { cur = d->materials[cur].first; ++depth; }
-            if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
-            depth = 0; cur = i;
-            while (is_mix(cur) && depth <= 4) { cur = d->materials[cur].second; ++depth; }
-            if (depth > 3) return fail(RTGPU_ERR_LIMIT, "mix materials nest deeper than 3");
+        const bool inner = m.type == RTGPU_MAT_CONSTMIX || m.type == RTGPU_MAT_FRESNELMIX || m.type == RTGPU_MAT_ADD;
+        if (inner && (m.first >= d->n_materials || m.second >= d->n_materials))
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix / add material child out of range");
+        if (m.type == RTGPU_MAT_ADD && d->materials[m.first].type != RTGPU_MAT_EMISSIVE)
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "the first child of an add material must be emissive");
+    }
+    // The shade stage resolves a material in at most 4 steps (mix and add materials above the leaf), and
+    // a glass material may have at most two mix levels above it (the reference keeps its per-vertex
+    // state in a tree of depth 3, utility/DynAllocTree.h:118-131).  A cycle exceeds both.
+    struct Walk {
+        const rtgpu_scene_desc* d;
+        const char* error = nullptr;
+        void visit(uint32_t mi, int steps, int mixes)
+        {
+            if (error) return;
+            const rtgpu_material& m = d->materials[mi];
+            const bool mix = m.type == RTGPU_MAT_CONSTMIX || m.type == RTGPU_MAT_FRESNELMIX;
+            if (mix || m.type == RTGPU_MAT_ADD) {
+                if (steps == 4) { error = "mix / add materials nest deeper than 4"; return; }
+                visit(m.first, steps + 1, mixes + (mix ? 1 : 0));
+                visit(m.second, steps + 1, mixes + (mix ? 1 : 0));
+            } else if (m.type == RTGPU_MAT_GLASS && mixes > 2) {
+                error = "glass material below more than two mix levels";
+            }
         }
+    };
+    for (uint32_t i = 0; i < d->n_materials; ++i) {
+        Walk w{d};
+        w.visit(i, 0, 0);
+        if (w.error) return fail(RTGPU_ERR_LIMIT, w.error);
     }
     return RTGPU_OK;
+}
+
+// IMaterial::hasVariance where it does not depend on the hit: 0 no, 1 yes, 2 hit-dependent
+// (DiffuseMaterial.cpp:228-247, GlossyMaterial.cpp:226-229, GlassMaterial.cpp:254-257, AddMaterial.cpp:25-28,
+// MixMaterial.cpp:59-65 with the constant factor of MixMaterial.h:19-26 narrowed to float)
+uint32_t material_variance(const rtgpu_scene_desc& d, uint32_t mi, int depth)
+{
+    const rtgpu_material& m = d.materials[mi];
+    if (depth > 4) return 0;
+    switch (m.type) {
+    case RTGPU_MAT_DIFFUSE: return 1;
+    case RTGPU_MAT_GLOSSY: return m.roughness > 0.0f ? 1 : 0;
+    case RTGPU_MAT_GLASS: return 1;
+    case RTGPU_MAT_ADD: {
+        const uint32_t a = material_variance(d, m.first, depth + 1), b = material_variance(d, m.second, depth + 1);
+        return (a == 1 || b == 1) ? 1 : ((a == 2 || b == 2) ? 2 : 0);
+    }
+    case RTGPU_MAT_CONSTMIX: {
+        const float f = (float)m.mix_factor;
+        if (f == 0.0f) return material_variance(d, m.first, depth + 1);
+        if (f == 1.0f) return material_variance(d, m.second, depth + 1);
+        return 1;
+    }
+    case RTGPU_MAT_FRESNELMIX: {
+        const uint32_t a = material_variance(d, m.first, depth + 1), b = material_variance(d, m.second, depth + 1);
+        return (a == 1 && b == 1) ? 1 : 2;
+    }
+    default: return 0;
+    }
 }
 
 int ceil_log2(uint32_t n)
@@ -407,7 +455,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         dm.second = m.second;
         dm.intensity = m.intensity;
         dm.texture = m.texture;
-        dm.pad = 0;
+        dm.variance = material_variance(*desc, i, 0);
     }
     std::vector<DevTexture> texs(desc->n_textures);
     std::vector<uint32_t> texels;
@@ -493,8 +541,11 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nAreaLights = desc->n_area_lights;
     v.nDirLights = desc->n_directional_lights;
     v.hasEnv = desc->has_environment ? 1 : 0;
-    for (uint32_t i = 0; i < desc->n_materials; ++i)
+    for (uint32_t i = 0; i < desc->n_materials; ++i) {
         if (desc->materials[i].type == RTGPU_MAT_FRESNELMIX) v.hasFresnelMix = 1;
+        if (desc->materials[i].type == RTGPU_MAT_GLASS) v.hasGlass = 1;
+        if (desc->materials[i].type == RTGPU_MAT_ADD) v.hasAdd = 1;
+    }
     // ColorEnvironment::getRadiance = color * intensity (RGB * double), ColorEnvironment.cpp:6-9
     for (int a = 0; a < 3; ++a) v.envRadiance[a] = (float)((double)desc->env_color[a] * desc->env_intensity);
     info.device_bytes = bytes;

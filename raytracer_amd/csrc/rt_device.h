@@ -16,7 +16,7 @@ struct DevMaterial {
     uint32_t first, second;
     double intensity;
     uint32_t texture;   // 1 + texture index (albedo / emission map), 0 = none
-    uint32_t pad;
+    uint32_t variance;  // IMaterial::hasVariance: 0 no, 1 yes, 2 depends on the hit (a Fresnel mix below decides)
 };
 
 struct DevTexture {
@@ -77,6 +77,8 @@ struct SceneView {
     uint32_t nMaterials, nPointLights, nAreaLights, nDirLights;
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
+    int32_t hasGlass;           // some material is glass: paths carry the extra records of a glass vertex
+    int32_t hasAdd;             // some material is an add material: paths carry a collected-emission record
     float envRadiance[3];
 };
 

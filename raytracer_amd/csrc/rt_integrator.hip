@@ -53,6 +53,9 @@ constexpr uint32_t ST_PASSED_VAR = 1u << 6;
 constexpr uint32_t ST_GLOSSY_PENDING = 1u << 7;
 constexpr uint32_t ST_GLOSSY_ROUGH = 1u << 8;
 constexpr uint32_t ST_RETRACE = 1u << 9;
+constexpr uint32_t ST_GLASS_PENDING = 1u << 10;   // a glass vertex waits for the hit of its own ray
+constexpr uint32_t ST_GLASS_INTERNAL = 1u << 11;  // ... and its transport direction points against the (flipped) normal
+constexpr uint32_t ST_GLASS_STICKY = 1u << 12;    // ... and a visibility query along its other direction is in flight
 
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
@@ -65,6 +68,14 @@ struct Pool {
     float4* thr;          // per path: throughput
     float4* aux;          // per path: pending contribution (shadow ray) or the glossy vertex's hit point
     float4* result;       // per path
+    // scenes with glass: normal used by the glass vertex (xyz) and the vertex's own t (w); the visibility
+    // query along the direction the vertex did not take (origin + limit, direction + light index / answer)
+    float4* glassN;
+    float4* glassA;
+    float4* glassB;
+    // scenes with add materials: emission collected so far; emission of a vertex whose divisor is decided later
+    float4* acc;
+    float4* accPend;
     // per sample (pixel, i): the primary ray and its hit
     float4* sA;           // origin, t
     float4* sB;           // direction
@@ -243,11 +254,12 @@ __device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance&
 // ---- shade -----------------------------------------------------------------------------------
 // FIRST: the batch's first pass -- lane q is path q, vertex 0 is its sample's primary hit, and
 // nothing has been written for the path yet.  Otherwise lane q shades path qIn[q].
+// RICH: the scene has glass or add materials (their code and registers are left out otherwise).
 // A path's result is stored when the path ends here (black unless it collected something); a path
 // that goes on through a shadow ray gets black here and its contribution from the shadow stage.
 constexpr int kShadeBlock = RT_SHADE_BLOCK;
 
-template <bool FIRST>
+template <bool FIRST, bool RICH>
 __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
                                                     const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
 {
@@ -287,11 +299,18 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
         // what the path leaves behind for the next stage
         float outTmax = 0.0f;
         F3 outAux = f3(0, 0, 0);
+        float outAuxW = 0.0f;
         bool writeThr = false, writeAux = false;
         bool passed = (state & ST_PASSED_VAR) != 0;
         bool done = false;
+        // A path that ends here either counts -- its value is `acc + result` -- or was cut by Russian
+        // roulette / the length limit, and then the whole path is black (renderer/Renderer.cpp:237-240).
         RGBf result = rgb(0, 0, 0);
-        bool haveResult = false;
+        bool completed = false;
+        // emission collected from add materials (material/AddMaterial.cpp:12-17) along the path
+        RGBf acc = rgb(0, 0, 0), pend = rgb(0, 0, 0);
+        bool writeAcc = FIRST, writePend = false;
+        if (!FIRST && (RICH && sv.hasAdd)) { const float4 aq = pool.acc[p]; acc = rgb(aq.x, aq.y, aq.z); }
 
         if (state & ST_GLOSSY_PENDING) {
             // GlossyMaterial::sampleTransport after its own traceRay (material/GlossyMaterial.cpp:126-178),
@@ -310,12 +329,13 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     if (area_light_hit(sv.areaLights[li], o, d, lt) && bestT > (double)lt) { lightIdx = (int)li; bestT = lt; }
                 }
             }
+            if ((RICH && sv.hasAdd)) { const float4 pq = pool.accPend[p]; pend = rgb(pq.x, pq.y, pq.z); }
             if (lightIdx >= 0) {
                 done = true;
-                if (!rough && k + 1 != maxLen) { // mirror: the light's irradiance / 2 (GlossyMaterial.cpp:198-203)
-                    result = rgb_mul(thr, rgb_scale_f(area_light_irradiance(sv.areaLights[lightIdx]), 1.0f / (float)2));
-                    haveResult = true;
-                }
+                completed = k + 1 != maxLen;
+                result = pend;
+                if (!rough) // mirror: the light's irradiance / 2 (GlossyMaterial.cpp:198-203)
+                    result = rgb_add(pend, rgb_mul(thr, rgb_scale_f(area_light_irradiance(sv.areaLights[lightIdx]), 1.0f / (float)2)));
             } else {
                 const uint32_t rs = i * M + (passed ? j : 0u);
                 const bool terminated = (k + 1 == maxLen) || rand_unit(st.seed, pixel, rs, (uint32_t)k, DIM_RR) < 0.2f;
@@ -324,6 +344,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 } else {
                     const float f = (rough ? 2.0f : 1.0f) * (1.0f / (1.0f - 0.2f));
                     thr = rgb_scale_f(thr, f);
+                    if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(pend, 1.0f - 0.2f)); writeAcc = true; }
                     state &= ~(ST_GLOSSY_PENDING | ST_GLOSSY_ROUGH);
                     if (!hit) {
                         // ctx.nextHit is empty: samplePath traces again from hitpoint + dir * 1e-4 (Renderer.cpp:57-61)
@@ -340,11 +361,67 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     }
                 }
             }
+        } else if (RICH && (state & ST_GLASS_PENDING)) {
+            // GlassMaterial::sampleTransport after its traceRay (material/GlassMaterial.cpp:109-132), the
+            // vertex's bsdf (:135-178) and the Russian roulette of samplePath (renderer/Renderer.cpp:52)
+            const float4 hq = pool.aux[p];
+            const F3 hp = f3(hq.x, hq.y, hq.z);
+            const DevMaterial& gm = sv.materials[__float_as_uint(hq.w)];
+            const float4 gn = pool.glassN[p];
+            if ((RICH && sv.hasAdd)) { const float4 pq = pool.accPend[p]; pend = rgb(pq.x, pq.y, pq.z); }
+            double bestT = hit ? (double)t : 1E99;
+            int lightIdx = -1;
+            for (uint32_t li = 0; li < sv.nAreaLights; ++li) {
+                float lt;
+                if (area_light_hit(sv.areaLights[li], o, d, lt) && bestT > (double)lt) { lightIdx = (int)li; bestT = lt; }
+            }
+            if (lightIdx < 0 && (state & ST_GLASS_STICKY)) {
+                // an earlier re-sampling pass of this vertex went the other way and met a light there: the
+                // vertex stays emissive with that light (the metadata's lightHit is never cleared, :115-122)
+                const uint32_t answer = __float_as_uint(pool.glassB[p].w);
+                if (answer != kInvalid) lightIdx = (int)answer;
+            }
+            const float metaT = (float)bestT;
+            RGBf atten = rgb(1.0f, 1.0f, 1.0f);
+            const bool internal = (state & ST_GLASS_INTERNAL) != 0;
+            if (internal) atten = rgb_pow_d(rgb(gm.color[0], gm.color[1], gm.color[2]), (double)gm.roughness * (double)metaT);
+            state &= ~(ST_GLASS_PENDING | ST_GLASS_INTERNAL | ST_GLASS_STICKY);
+            if (lightIdx >= 0) {
+                done = true;
+                completed = k + 1 != maxLen;
+                const DevAreaLight& L = sv.areaLights[lightIdx];
+                const RGBf lightRadiance = rgb_div_d(area_light_irradiance(L), RT_PI);
+                const F3 lampPoint = d * metaT;   // as the reference has it: not offset by the hit point
+                const F3 objectToLamp = normalized3(lampPoint - hp);
+                const float angle = fmaxf(0.0f, dot3(f3(gn.x, gn.y, gn.z), objectToLamp));
+                RGBf val = rgb_scale_d(lightRadiance, (double)angle);
+                if (internal) val = rgb_mul(val, atten);
+                result = rgb_add(pend, rgb_mul(thr, val));
+            } else {
+                const uint32_t rs = i * M + (passed ? j : 0u);
+                const bool terminated = (k + 1 == maxLen) || rand_unit(st.seed, pixel, rs, (uint32_t)k, DIM_RR) < 0.1f;
+                if (terminated) {
+                    done = true;
+                } else {
+                    thr = rgb_div_f(rgb_mul(thr, atten), 1.0f - 0.1f);
+                    if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(pend, 1.0f - 0.1f)); writeAcc = true; }
+                    if (!hit) {
+                        // the reference traces the same ray once more (Renderer.cpp:57-61) and it misses again
+                        done = true;
+                        completed = true;
+                        if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
+                    } else {
+                        k += 1;
+                        state = (state & ~ST_K_MASK) | (uint32_t)k;
+                    }
+                }
+            }
         } else if (state & ST_RETRACE) {
             state &= ~ST_RETRACE;
             if (!hit) {
                 done = true;
-                if (sv.hasEnv) { result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2])); haveResult = true; }
+                completed = true;
+                if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
             } else {
                 k += 1;
                 state = (state & ~ST_K_MASK) | (uint32_t)k;
@@ -353,7 +430,8 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             // the extension ray left the scene: the path ends at the previous vertex and collects
             // the environment along its transport direction (renderer/Renderer.cpp:73-76, 94-98)
             done = true;
-            if (sv.hasEnv) { result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2])); haveResult = true; }
+            completed = true;
+            if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
         }
 
         if (!done) {
@@ -378,26 +456,47 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             if (curVar && j == 0) pool.sHasVar[s] = 1;
             const uint32_t rs = i * M + (passed ? j : 0u);
             const uint32_t vk = (uint32_t)k;
-            // MixMaterial::sampleTransport (material/MixMaterial.cpp:9-26)
-            for (uint32_t level = 0; level < 4 && mat_is_mix(sv.materials[mi]); ++level) {
+            // The walk from the hit's material to the closure that samples this vertex:
+            // MixMaterial::sampleTransport picks a child (material/MixMaterial.cpp:9-26), AddMaterial goes on
+            // with its second child and adds its emissive first child to the vertex (material/AddMaterial.cpp:5-17).
+            // walkBits names the walk, two bits per step: 1 / 2 = mix chose its second / first child, 3 = add.
+            const uint32_t rootMi = mi;
+            uint32_t walkBits = 0;
+            RGBf addE = rgb(0, 0, 0);
+            auto surface_color = [&](const DevMaterial& m) {
+                RGBf c = rgb(m.color[0], m.color[1], m.color[2]);
+                if (m.texture != 0u && (m.type == RTGPU_MAT_DIFFUSE || m.type == RTGPU_MAT_EMISSIVE)) {
+                    float tu, tv;
+                    hit_texcoord(sv, slot, beta, gamma, tu, tv);
+                    c = m.type == RTGPU_MAT_DIFFUSE ? albedo_lookup(sv, m.texture - 1u, tu, tv) : emission_lookup(sv, m.texture - 1u, tu, tv);
+                }
+                return c;
+            };
+            for (uint32_t level = 0; level < 4; ++level) {
                 const DevMaterial& mm = sv.materials[mi];
-                const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
-                mi = choseFirst ? mm.first : mm.second;
+                if (mat_is_mix(mm)) {
+                    const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
+                    walkBits |= (choseFirst ? 2u : 1u) << (2u * level);
+                    mi = choseFirst ? mm.first : mm.second;
+                } else if (RICH && mm.type == RTGPU_MAT_ADD) {
+                    const DevMaterial& em = sv.materials[mm.first];
+                    addE = rgb_add(addE, rgb_scale_d(surface_color(em), em.intensity));
+                    walkBits |= 3u << (2u * level);
+                    mi = mm.second;
+                } else {
+                    break;
+                }
             }
             const DevMaterial& mat = sv.materials[mi];
-            RGBf color = rgb(mat.color[0], mat.color[1], mat.color[2]);
-            if (mat.texture != 0u && (mat.type == RTGPU_MAT_DIFFUSE || mat.type == RTGPU_MAT_EMISSIVE)) {
-                float tu, tv;
-                hit_texcoord(sv, slot, beta, gamma, tu, tv);
-                color = mat.type == RTGPU_MAT_DIFFUSE ? albedo_lookup(sv, mat.texture - 1u, tu, tv) : emission_lookup(sv, mat.texture - 1u, tu, tv);
-            }
+            const RGBf color = surface_color(mat);
             const F3 hitpoint = o + (d * t); // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
             const bool lastVertex = (k + 1 == maxLen); // such a path is "terminated" and contributes nothing
 
             if (mat.type == RTGPU_MAT_EMISSIVE) {
                 // EmissiveMaterial (material/EmissiveMaterial.cpp:5-22)
                 done = true;
-                if (!lastVertex) { result = rgb_mul(thr, rgb_scale_d(color, mat.intensity)); haveResult = true; }
+                completed = !lastVertex;
+                result = rgb_mul(thr, rgb_add(addE, rgb_scale_d(color, mat.intensity)));
             } else if (lastVertex) {
                 done = true;
             } else if (mat.type == RTGPU_MAT_TRANSPARENT) {
@@ -405,6 +504,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 // Russian roulette 0.01 (renderer/Renderer.cpp:52, 104-107)
                 done = true;
                 if (!(rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.01f)) {
+                    if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.01f)); writeAcc = true; }
                     thr = rgb_div_f(thr, 1.0f - 0.01f);
                     o = hitpoint + (d * 0.0001f);
                     writeThr = true;
@@ -413,17 +513,115 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 }
             } else {
                 if (!sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
-                if (mat.type == RTGPU_MAT_DIFFUSE) {
+                if (RICH && mat.type == RTGPU_MAT_GLASS) {
+                    // GlassMaterial::sampleTransport up to its traceRay (material/GlassMaterial.cpp:21-107)
+                    const F3 objToIncoming = -d;
+                    const F3 reflDir = (-objToIncoming) + ((float)(2.0 * (double)dot3(normal, objToIncoming)) * normal);
+                    double nDotWo = dot3(normal, objToIncoming);
+                    double incomingAngle = nDotWo;
+                    const bool internalIn = nDotWo < 0;
+                    double curRelIor = mat.intensity / 1.0;
+                    if (internalIn) curRelIor = 1.0 / curRelIor;
+                    const double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+                    const bool tir = cosTransmissionSqr < 0;
+                    float reflW = 1.0f;
+                    F3 transDir = reflDir, nUsed = normal;
+                    if (!tir) {
+                        if (internalIn) { nDotWo = -nDotWo; incomingAngle = -incomingAngle; nUsed = -normal; } // the node's normal is flipped for good (:73-78)
+                        const double cosRefractAngle = sqrt(cosTransmissionSqr);
+                        transDir = (d / (float)curRelIor) - ((float)(cosRefractAngle - (incomingAngle / curRelIor)) * nUsed);
+                        const double rs_ = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+                        const double rp_ = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+                        const double kr = ((rs_ * rs_) + (rp_ * rp_)) / 2.0;
+                        const double reflectionWeight = kr, transmissionWeight = 1.0 - kr;
+                        reflW = (float)(reflectionWeight / (reflectionWeight + transmissionWeight));
+                    }
+                    const bool reflect = rand_unit(st.seed, pixel, rs, vk, DIM_GLASS) < reflW;
+                    // The reference keeps this state in the node's metadata, and the node that is re-sampled
+                    // materialAA times (the sample's first variance vertex) keeps its metadata from pass to pass
+                    // (:26-29, renderer/Renderer.cpp:246).  What an earlier pass left behind follows from its
+                    // random numbers: did it reach this closure, and which of the two directions did it take.
+                    bool firstVisit = true, otherBefore = false;
+                    if (isFirstVar) {
+                        for (uint32_t jj = 0; jj < j; ++jj) {
+                            const uint32_t rsj = i * M + jj;
+                            uint32_t m2 = rootMi, bits2 = 0;
+                            for (uint32_t level = 0; level < 4; ++level) {
+                                const DevMaterial& mm = sv.materials[m2];
+                                if (mat_is_mix(mm)) {
+                                    const bool choseFirst = rand_unit(st.seed, pixel, rsj, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
+                                    bits2 |= (choseFirst ? 2u : 1u) << (2u * level);
+                                    m2 = choseFirst ? mm.first : mm.second;
+                                } else if (mm.type == RTGPU_MAT_ADD) {
+                                    bits2 |= 3u << (2u * level);
+                                    m2 = mm.second;
+                                } else {
+                                    break;
+                                }
+                            }
+                            if (bits2 != walkBits) continue;
+                            firstVisit = false;
+                            if ((rand_unit(st.seed, pixel, rsj, vk, DIM_GLASS) < reflW) != reflect) otherBefore = true;
+                        }
+                    }
+                    done = true;
+                    if (tir && firstVisit) {
+                        // total internal reflection, first visit (:62-70): no look for lights, the vertex is an
+                        // ordinary bounce and absorbs over its own incoming distance (meta->t is NaN, :173)
+                        if (!(rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.1f)) {
+                            RGBf atten = rgb(1.0f, 1.0f, 1.0f);
+                            if (dot3(normal, reflDir) < 0) atten = rgb_pow_d(color, (double)mat.roughness * (double)t);
+                            if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
+                            thr = rgb_div_f(rgb_mul(thr, atten), 1.0f - 0.1f);
+                            o = hitpoint + (reflDir * 0.0001f);
+                            d = reflDir;
+                            writeThr = true;
+                            state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
+                            pushExt = true;
+                        }
+                    } else {
+                        const F3 dir = reflect ? reflDir : transDir;
+                        if ((RICH && sv.hasAdd)) { pend = rgb_mul(thr, addE); writePend = true; }
+                        state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLASS_PENDING | (dot3(nUsed, dir) < 0 ? ST_GLASS_INTERNAL : 0u);
+                        if (!firstVisit && otherBefore) {
+                            // an earlier pass looked for lights along the other direction (:109-122)
+                            const F3 other = reflect ? transDir : reflDir;
+                            const F3 o2 = hitpoint + (other * 0.0001f);
+                            double bestT = 1E99;
+                            int lightIdx = -1;
+                            for (uint32_t li = 0; li < sv.nAreaLights; ++li) {
+                                float lt;
+                                if (area_light_hit(sv.areaLights[li], o2, other, lt) && bestT > (double)lt) { lightIdx = (int)li; bestT = lt; }
+                            }
+                            if (lightIdx >= 0) {
+                                pool.glassA[p] = f4(o2.x, o2.y, o2.z, (float)bestT);
+                                pool.glassB[p] = f4(other.x, other.y, other.z, __uint_as_float((uint32_t)lightIdx));
+                                state |= ST_GLASS_STICKY;
+                                pushShadow = true;
+                            }
+                        }
+                        pool.glassN[p] = f4(nUsed.x, nUsed.y, nUsed.z, t);
+                        o = hitpoint + (dir * 0.0001f);
+                        d = dir;
+                        outAux = hitpoint;
+                        outAuxW = __uint_as_float(mi);
+                        writeAux = true;
+                        writeThr = true;
+                        pushExt = true;
+                    }
+                } else if (mat.type == RTGPU_MAT_DIFFUSE) {
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;
                     if (useNEE) {
                         const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
                         done = true;
+                        completed = true;
+                        result = rgb_mul(thr, addE);   // what the vertex is worth when the light is hidden
                         if (ns.valid) {
                             const double angle = fmaxf(0.0f, dot3(normal, ns.dir));
                             const RGBf direct = rgb_scale_d(ns.radiance, angle);
                             const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensity / RT_PI), 2.0f);
-                            const RGBf c = rgb_mul(thr, rgb_mul(color, value));
+                            const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, rgb_mul(color, value))));
                             o = hitpoint + (ns.dir * 0.0001f);
                             d = ns.dir;
                             outTmax = ns.tmax;
@@ -445,6 +643,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             const double angle = fmaxf(0.0f, dot3(normal, dir));
                             const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
                             const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
+                            if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
                             thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
                             o = hitpoint + (dir * 0.0001f);
                             d = dir;
@@ -461,12 +660,14 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     if (useNEE) {
                         const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
                         done = true;
+                        completed = true;
+                        result = rgb_mul(thr, addE);
                         if (ns.valid) {
                             const F3 micro = normalized3((-d) + ns.dir);
                             const double angle = fmaxf(0.0f, dot3(micro, ns.dir));
                             const float f = ggx_brdf(roughness, -d, ns.dir, normal, micro);
                             const RGBf neeRadiance = rgb_scale_d(rgb_scale_d(ns.radiance, angle), f);
-                            const RGBf c = rgb_mul(thr, rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color));
+                            const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color))));
                             o = hitpoint + (ns.dir * 0.0001f);
                             d = ns.dir;
                             outTmax = ns.tmax;
@@ -482,7 +683,10 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         // getPerfectReflectionDir (GlossyMaterial.cpp:22-25): the double factor narrows to float
                         const F3 sampleDir = d + ((float)(2.0 * (double)dot3(micro, -d)) * micro);
                         done = true;
+                        completed = true;   // a direction below the surface ends the path as an emissive black vertex (GlossyMaterial.cpp:117-122)
+                        result = rgb_mul(thr, addE);
                         if (!(dot3(sampleDir, normal) < 0)) {
+                            if ((RICH && sv.hasAdd)) { pend = rgb_mul(thr, addE); writePend = true; }
                             thr = rgb_mul(thr, color);
                             o = hitpoint + (sampleDir * 0.001f);
                             d = sampleDir;
@@ -501,9 +705,16 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
             pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
             if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
-            if (writeAux) pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, 0.0f);
+            if (writeAux) pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
+            if ((RICH && sv.hasAdd) && pushExt) {
+                if (writeAcc) pool.acc[p] = f4(acc.r, acc.g, acc.b, 0.0f);
+                if (writePend) pool.accPend[p] = f4(pend.r, pend.g, pend.b, 0.0f);
+            }
         }
-        if (!pushExt) pool.result[p] = haveResult ? f4(result.r, result.g, result.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (!pushExt) {
+            const RGBf total = rgb_add(acc, result);
+            pool.result[p] = completed ? f4(total.r, total.g, total.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
+        }
     }
     queue_push2<kShadeBlock>(qExt, pool.counters + 0, pushExt, pool.qShadow, pool.counters + 1, pushShadow, p);
     // Extension rays of vertices before the first variance vertex are identical for every material
@@ -523,9 +734,17 @@ __device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& po
     const uint32_t q = block * 64u + lane;
     const bool has = q < n;
     const uint32_t p = pool.qShadow[has ? q : 0u];
-    const float4 ra = pool.rayA[p], rb = pool.rayB[p];
+    float4 ra = pool.rayA[p], rb = pool.rayB[p];
+    // a glass vertex asks whether the light along the direction it did not take is visible
+    const bool sticky = sv.hasGlass && (__float_as_uint(rb.w) & ST_GLASS_STICKY) != 0;
+    if (sticky) { ra = pool.glassA[p]; rb = pool.glassB[p]; }
     const bool occluded = wave_any<INSTANCED>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), ra.w, lds, lane);
-    if (has && !occluded) pool.result[p] = pool.aux[p];
+    if (!has) return;
+    if (sticky) {
+        if (occluded) pool.glassB[p] = f4(rb.x, rb.y, rb.z, __uint_as_float(kInvalid));
+    } else if (!occluded) {
+        pool.result[p] = pool.aux[p];
+    }
 }
 
 template <bool INSTANCED>
@@ -691,6 +910,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         pool.rayA = ws.alloc<float4>(P); pool.rayB = ws.alloc<float4>(P); pool.hit = ws.alloc<float4>(P);
         pool.hitInst = ws.alloc<uint32_t>(sv.singleMesh ? 1 : P);
         pool.thr = ws.alloc<float4>(P); pool.aux = ws.alloc<float4>(P); pool.result = ws.alloc<float4>(P);
+        pool.glassN = ws.alloc<float4>(sv.hasGlass ? P : 1); pool.glassA = ws.alloc<float4>(sv.hasGlass ? P : 1); pool.glassB = ws.alloc<float4>(sv.hasGlass ? P : 1);
+        pool.acc = ws.alloc<float4>(sv.hasAdd ? P : 1); pool.accPend = ws.alloc<float4>(sv.hasAdd ? P : 1);
         pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
         pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
         pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
@@ -699,6 +920,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
+        const bool rich = sv.hasGlass || sv.hasAdd;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
             Batch batch;
@@ -716,8 +938,14 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             // at most one glossy re-trace step per vertex on top of the vertex steps
             for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
                 if (step > 0) LN_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), ls));
-                if (step == 0) hipLaunchKernelGGL((shade_kernel<true>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
-                else hipLaunchKernelGGL((shade_kernel<false>), dim3((nActive + kShadeBlock - 1) / kShadeBlock), dim3(kShadeBlock), 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                const dim3 shadeGrid((nActive + kShadeBlock - 1) / kShadeBlock), shadeBlock(kShadeBlock);
+                if (rich) {
+                    if (step == 0) hipLaunchKernelGGL((shade_kernel<true, true>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                    else hipLaunchKernelGGL((shade_kernel<false, true>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                } else {
+                    if (step == 0) hipLaunchKernelGGL((shade_kernel<true, false>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                    else hipLaunchKernelGGL((shade_kernel<false, false>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
+                }
                 LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
                 LN_TRY(hipStreamSynchronize(ls));
                 const uint32_t nExt = h[0], nShadow = h[1], nRepeated = h[3];

@@ -14,7 +14,7 @@ namespace rt {
 enum RngDim : uint32_t {
     DIM_CAM_X = 0, DIM_CAM_Y = 1, DIM_LENS_X = 2, DIM_LENS_Y = 3, DIM_LENS_Z = 4,   // with vertex = kVertexCamera
     DIM_NEE_CHOICE = 1, DIM_LIGHT_TYPE = 2, DIM_LIGHT_INDEX = 3, DIM_AREA_U = 4, DIM_AREA_V = 5,
-    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_MIX0 = 12
+    DIM_SQUARE_X = 6, DIM_SQUARE_Y = 7, DIM_RR = 8, DIM_DIR_ALPHA = 9, DIM_DIR_BETA = 10, DIM_GLASS = 11, DIM_MIX0 = 12
 };
 constexpr uint32_t kVertexCamera = 255;
 

@@ -317,48 +317,34 @@ __device__ __forceinline__ float mat_mix_factor(const DevMaterial& M, F3 normal,
 }
 
 // IMaterial::hasVariance: Diffuse true (DiffuseMaterial.cpp:228-247 without photon map), Glossy
-// roughness > 0 (GlossyMaterial.cpp:226-229), Emissive and Transparent false, Mix
-// (MixMaterial.cpp:59-65; the factor of a Fresnel mix depends on the hit).
+// roughness > 0 (GlossyMaterial.cpp:226-229), Glass true (GlassMaterial.cpp:254-257), Emissive and
+// Transparent false, Add first || second (AddMaterial.cpp:25-28), Mix: unless (factor==0 && !first)
+// || (factor==1 && !second) (MixMaterial.cpp:59-65).  DevMaterial::variance holds the answer for
+// materials where it does not depend on the hit (0 / 1); 2 = a Fresnel mix decides per hit.  Mix and
+// add materials nest at most 4 deep (checked at scene creation), so the recursion is unrolled.
+template <int DEPTH>
+__device__ __forceinline__ bool mat_variance_at(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir)
+{
+    const DevMaterial& M = sv.materials[mi];
+    if (M.variance != 2u) return M.variance != 0u;
+    if constexpr (DEPTH == 0) {
+        return false;
+    } else {
+        if (M.type == RTGPU_MAT_ADD)
+            return mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir) || mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir);
+        const float f = mat_mix_factor(M, normal, incomingDir);
+        const bool noVar = (f == 0.0f && !mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir)) ||
+                           (f == 1.0f && !mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir));
+        return !noVar;
+    }
+}
 __device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir)
 {
-    // A mix has variance unless (factor==0 && !first.var) || (factor==1 && !second.var).  Mixes nest
-    // at most 3 deep (checked at scene creation), so the recursion is expanded by hand.
-    struct Eval {
-        const SceneView& sv;
-        F3 n, d;
-        __device__ bool leaf(uint32_t m) const
-        {
-            const DevMaterial& M = sv.materials[m];
-            if (M.type == RTGPU_MAT_DIFFUSE) return true;
-            if (M.type == RTGPU_MAT_GLOSSY) return M.roughness > 0.0f;
-            return false;
-        }
-        __device__ bool l3(uint32_t m) const
-        {
-            const DevMaterial& M = sv.materials[m];
-            if (!mat_is_mix(M)) return leaf(m);
-            const float f = mat_mix_factor(M, n, d);
-            const bool noVar = (f == 0.0f && !leaf(M.first)) || (f == 1.0f && !leaf(M.second));
-            return !noVar;
-        }
-        __device__ bool l2(uint32_t m) const
-        {
-            const DevMaterial& M = sv.materials[m];
-            if (!mat_is_mix(M)) return leaf(m);
-            const float f = mat_mix_factor(M, n, d);
-            const bool noVar = (f == 0.0f && !l3(M.first)) || (f == 1.0f && !l3(M.second));
-            return !noVar;
-        }
-        __device__ bool l1(uint32_t m) const
-        {
-            const DevMaterial& M = sv.materials[m];
-            if (!mat_is_mix(M)) return leaf(m);
-            const float f = mat_mix_factor(M, n, d);
-            const bool noVar = (f == 0.0f && !l2(M.first)) || (f == 1.0f && !l2(M.second));
-            return !noVar;
-        }
-    };
-    return Eval{sv, normal, incomingDir}.l1(mi);
+    return mat_variance_at<4>(sv, mi, normal, incomingDir);
 }
+
+__device__ __forceinline__ RGBf rgb_add(RGBf a, RGBf b) { return RGBf{a.r + b.r, a.g + b.g, a.b + b.b}; } // RGB::operator+, film/RGB.h:93-105
+// RGB::pow(double), film/RGB.h:85-88
+__device__ __forceinline__ RGBf rgb_pow_d(RGBf a, double power) { return RGBf{(float)pow((double)a.r, power), (float)pow((double)a.g, power), (float)pow((double)a.b, power)}; }
 
 } // namespace rt

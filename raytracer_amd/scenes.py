@@ -12,7 +12,7 @@ import math
 
 import numpy as np
 
-from .abi import (MAT_CONSTMIX, MAT_DIFFUSE, MAT_EMISSIVE, MAT_FRESNELMIX, MAT_GLOSSY, MAT_TRANSPARENT, SHAPE_SPHERE,
+from .abi import (MAT_ADD, MAT_CONSTMIX, MAT_DIFFUSE, MAT_EMISSIVE, MAT_FRESNELMIX, MAT_GLASS, MAT_GLOSSY, MAT_TRANSPARENT, SHAPE_SPHERE,
                   InstanceData, MaterialData, MeshData, SceneData)
 
 
@@ -409,6 +409,48 @@ def coat_scene():
                           np.concatenate([mesh.indices, pane_f + np.uint32(nv)]),
                           np.concatenate([tm, np.full(len(pane_f), base + 3, dtype=np.uint32)]))]
     return sc, cam_m, yfov
+
+
+def glass_scene(view="room"):
+    """The box of box_scene with glass and add materials (view="pane": the camera looks up at the area light
+    through the pane, so most glass vertices are re-sampled ones whose transmitted ray runs into the light): a solid glass sphere (absorbing), a sphere that is
+    half diffuse / half glass (constant mix, as a glTF transmission factor builds it) under a faint emission
+    (add material), a glass pane right below the area light (seen from behind: internal rays, total internal
+    reflection at grazing angles, transmitted rays that run into the light), a glowing left wall (emission added
+    to green diffuse) and a floor whose emission is added to a diffuse / rough glossy mix."""
+    sc, cam_m, yfov = box_scene()
+    base = len(sc.materials)
+    sc.materials += [
+        MaterialData(MAT_GLASS, (0.75, 0.95, 0.85), intensity=1.5, roughness=2.0),   # base+0: ior 1.5, attenuation 2
+        MaterialData(MAT_CONSTMIX, mix_factor=0.5, first=0, second=base + 0),         # base+1: transmission 0.5
+        MaterialData(MAT_EMISSIVE, (0.05, 0.1, 0.3), intensity=1.0),                  # base+2
+        MaterialData(MAT_ADD, first=base + 2, second=base + 1),                       # base+3: emission + (diffuse | glass)
+        MaterialData(MAT_GLASS, (1.0, 1.0, 1.0), intensity=1.33, roughness=5.0),      # base+4: clear pane
+        MaterialData(MAT_ADD, first=base + 2, second=3),                              # base+5: emission + green diffuse
+        MaterialData(MAT_CONSTMIX, mix_factor=0.4, first=0, second=1),                # base+6: diffuse | rough glossy
+        MaterialData(MAT_EMISSIVE, (0.2, 0.05, 0.02), intensity=0.5),                 # base+7
+        MaterialData(MAT_ADD, first=base + 7, second=base + 6),                       # base+8: emission + mix
+    ]
+    mesh = sc.meshes[0]
+    tm = mesh.tri_material.copy()
+    n = 6
+    quad = 2 * n * n
+    tm[0:quad] = base + 8                      # floor
+    tm[4 * quad:5 * quad] = base + 5           # left wall
+    nsph = (len(tm) - 6 * quad) // 2
+    tm[6 * quad:6 * quad + nsph] = base + 0    # first sphere: glass
+    tm[6 * quad + nsph:] = base + 3            # second sphere
+    pane_v, pane_f = grid_quad((1.0, 3.0, 0.5), (2.0, 0.0, 0.0), (0.0, 0.0, 2.0), 2, 2)
+    pane_v = np.asarray(pane_v, dtype=np.float32)
+    pane_f = np.asarray(pane_f, dtype=np.uint32)
+    nv = len(mesh.vertices)
+    sc.meshes = [MeshData(np.concatenate([mesh.vertices, pane_v]),
+                          np.concatenate([mesh.normals, vertex_normals(pane_v, pane_f)]),
+                          np.concatenate([mesh.indices, pane_f + np.uint32(nv)]),
+                          np.concatenate([tm, np.full(len(pane_f), base + 4, dtype=np.uint32)]))]
+    if view == "pane":
+        return sc, look_at((2.2, 0.3, 2.9), (2.0, 3.95, 1.8), up=(0.0, 0.0, -1.0)), 0.7
+    return sc, look_at((2.0, 1.0, 3.9), (2.0, 2.4, 0.5)), yfov
 
 
 def sun_scene(lights="sun+point"):

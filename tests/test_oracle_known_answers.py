@@ -326,3 +326,69 @@ def test_emission_map_texels_land_where_the_texture_coordinates_say():
             u, vv = (px + 0.5) / 32, 1.0 - (py + 0.5) / 32
             want[py, px] = tex[int(vv * 4), int(u * 4), :3].astype(np.float32) / 255.0 * 2.0
     assert np.allclose(img, want, rtol=1e-6, atol=1e-7)
+
+
+def _pane_scene(materials, pane_material, wall_material, panes=(-2.0,), wall_z=-4.0):
+    """Square panes at the given z (normal towards the camera at the origin) in front of a wall at wall_z."""
+    from raytracer_amd.abi import InstanceData, MeshData, SceneData
+    verts, idx, tm = [], [], []
+    for z, mat in [(z, pane_material) for z in panes] + [(wall_z, wall_material)]:
+        b = len(verts)
+        verts += [[-50, -50, z], [50, -50, z], [50, 50, z], [-50, 50, z]]
+        idx += [[b, b + 1, b + 2], [b, b + 2, b + 3]]
+        tm += [mat, mat]
+    v = np.array(verts, np.float32)
+    sc = SceneData()
+    sc.meshes = [MeshData(v, np.tile(np.array([[0, 0, 1]], np.float32), (len(v), 1)), np.array(idx, np.uint32), np.array(tm, np.uint32))]
+    sc.materials = materials
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    return sc
+
+
+def test_glass_slab_transmits_the_fresnel_series():
+    """GlassMaterial (material/GlassMaterial.cpp:21-178) at normal incidence on a clear slab of index 1.5: each
+    face reflects R = ((n - 1) / (n + 1))^2 = 0.04, and the light of an emissive wall behind the slab arrives as
+    (1 - R)^2 (1 + R^2 + R^4 + ...) = (1 - R) / (1 + R) = 0.923077 of its radiance (all internal reflections
+    included; the Russian roulette of every vertex is compensated, renderer/Renderer.cpp:104-107)."""
+    from raytracer_amd.abi import MAT_EMISSIVE, MAT_GLASS, MaterialData
+    sc = _pane_scene([MaterialData(MAT_GLASS, (1.0, 1.0, 1.0), intensity=1.5, roughness=5.0),
+                      MaterialData(MAT_EMISSIVE, (1.0, 0.5, 0.25), intensity=2.0)], 0, 1, panes=(-2.0, -2.5))
+    # the back face of the slab must face away from the camera: flip its normals
+    sc.meshes[0].normals[4:8] = (0, 0, -1)
+    cam = oracle.camera_from_transform(2.0, np.eye(4))   # a 2 degree cone around the axis: normal incidence
+    img, _ = oracle.OracleScene(sc).render(cam, abi.make_settings(48, 48, geometry_aa=16, material_aa=4, max_path_length=40,
+                                                                 jitter_mode=abi.JITTER_CENTER, seed=5))
+    mean = img.reshape(-1, 3).mean(axis=0)
+    want = np.array([1.0, 0.5, 0.25]) * 2.0 * (0.96 / 1.04)
+    assert np.allclose(mean, want, rtol=0.01)
+
+
+def test_glass_absorbs_along_the_ray_that_leaves_the_vertex():
+    """Index 1 (no reflection, no bending): the bsdf multiplies by color^(attenuationStrength * t) whenever the
+    transport direction points against the vertex's normal, t being the length of the ray that leaves the
+    vertex (material/GlassMaterial.cpp:120, 171-175).  The front face absorbs over the slab's thickness, and the
+    back face -- its normal was flipped for the internal ray (:73-78) -- over the distance to the wall."""
+    from raytracer_amd.abi import MAT_EMISSIVE, MAT_GLASS, MaterialData
+    color, strength = np.array([0.5, 0.8, 1.0]), 2.0
+    sc = _pane_scene([MaterialData(MAT_GLASS, tuple(color), intensity=1.0, roughness=strength),
+                      MaterialData(MAT_EMISSIVE, (1.0, 1.0, 1.0), intensity=1.0)], 0, 1, panes=(-2.0, -2.5), wall_z=-3.25)
+    sc.meshes[0].normals[4:8] = (0, 0, -1)
+    cam = oracle.camera_from_transform(1.0, np.eye(4))
+    img, _ = oracle.OracleScene(sc).render(cam, abi.make_settings(32, 32, geometry_aa=16, material_aa=2, jitter_mode=abi.JITTER_CENTER, seed=2))
+    mean = img.reshape(-1, 3).mean(axis=0)
+    want = color ** (strength * 0.5) * color ** (strength * 0.75)
+    assert np.allclose(mean, want, rtol=0.02)   # Russian roulette noise (two vertices, 10 % each)
+
+
+def test_add_material_adds_its_emission_to_what_the_path_brings():
+    """AddMaterial (material/AddMaterial.cpp:5-17) as io/GLTF.cpp:435-441 builds it: an emissive first child on
+    top of the surface's own material.  Over a transparent second child the pixel is the pane's emission plus
+    the radiance of the wall behind it."""
+    from raytracer_amd.abi import MAT_ADD, MAT_EMISSIVE, MAT_TRANSPARENT, MaterialData
+    sc = _pane_scene([MaterialData(MAT_EMISSIVE, (0.2, 0.4, 0.1), intensity=1.5), MaterialData(MAT_TRANSPARENT),
+                      MaterialData(MAT_ADD, first=0, second=1), MaterialData(MAT_EMISSIVE, (1.0, 0.5, 0.25), intensity=2.0)], 2, 3)
+    cam = oracle.camera_from_transform(30.0, np.eye(4))
+    img, _ = oracle.OracleScene(sc).render(cam, abi.make_settings(32, 32, geometry_aa=16, material_aa=1, jitter_mode=abi.JITTER_CENTER, seed=9))
+    mean = img.reshape(-1, 3).mean(axis=0)
+    want = np.array([0.2, 0.4, 0.1]) * 1.5 + np.array([1.0, 0.5, 0.25]) * 2.0
+    assert np.allclose(mean, want, rtol=0.01)   # Russian roulette of the transparent vertex: 1 %
