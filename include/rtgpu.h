@@ -95,6 +95,10 @@ typedef struct rtgpu_material {
     double mix_factor;  /* const mix: 0 = 100 % first, 1 = 100 % second */
     uint32_t first;     /* children of a const / fresnel mix or of an add material (material ids) */
     uint32_t second;
+    uint32_t normal_map; /* 1 + index into textures[] of the diffuse / glossy normalMap (material/NormalMapSampler.h:7-21,
+                          * DiffuseMaterial.cpp:33-37, GlossyMaterial.cpp:81-85); 0 = none.  Needs mesh texcoords: the
+                          * tangent comes from them (shape/TriangleMesh.cpp:130-139) */
+    uint32_t reserved;
 } rtgpu_material;
 
 typedef struct rtgpu_point_light { /* light/PointLight.h:9-22 (world space) */

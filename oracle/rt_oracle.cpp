@@ -599,6 +599,7 @@ struct SceneHit { // SceneRayHitInfo + RayHitInfo
     uint32_t prim = RTGPU_INVALID_ID; // original triangle index
     float beta = 0, gamma = 0;
     float u = 0, v = 0;   // RayHitInfo::texCoord
+    V3 tangent{};         // RayHitInfo::tangent, world space (InstancedModelList.cpp:131); zero for spheres (unset in the reference, Sphere.cpp:56)
     V3 hitpoint() const { return ro + (rd * (float)t); } // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
 };
 
@@ -679,6 +680,23 @@ bool instances_visibility(const orc_scene& S, uint32_t begin, uint32_t end, V3 o
     return false;
 }
 
+// RayHitInfo::tangent of a triangle, shape/TriangleMesh.cpp:130-146: row 0 of uvMat^-1 * deltaPosMat (2x2 inverse
+// = adjugate / determinant), or b - a for a mesh without texture coordinates
+V3 mesh_tangent(const Mesh& m, uint32_t tri)
+{
+    const V3 a = m.vertices[m.indices[3 * tri]], b = m.vertices[m.indices[3 * tri + 1]], c = m.vertices[m.indices[3 * tri + 2]];
+    if (m.texCoords.empty()) return b - a;
+    const float* ta = &m.texCoords[2 * m.indices[3 * tri]];
+    const float* tb = &m.texCoords[2 * m.indices[3 * tri + 1]];
+    const float* tc = &m.texCoords[2 * m.indices[3 * tri + 2]];
+    const float m00 = tb[0] - ta[0], m01 = tb[1] - ta[1], m10 = tc[0] - ta[0], m11 = tc[1] - ta[1];
+    const float det = (m00 * m11) - (m10 * m01);
+    const float invdet = 1.0f / det;
+    const float i00 = m11 * invdet, i01 = -m01 * invdet;
+    const V3 d0 = b - a, d1 = c - a;
+    return V3{(i00 * d0.x) + (i01 * d1.x), (i00 * d0.y) + (i01 * d1.y), (i00 * d0.z) + (i01 * d1.z)};
+}
+
 // Scene::traceRay, scene/renderable/Scene.cpp:14-17
 SceneHit scene_trace(const orc_scene& S, V3 o, V3 d)
 {
@@ -708,6 +726,7 @@ SceneHit scene_trace(const orc_scene& S, V3 o, V3 d)
             r.u = ((alfa * ta[0]) + (ih.beta * tb[0])) + (ih.gamma * tc[0]);
             r.v = ((alfa * ta[1]) + (ih.beta * tb[1])) + (ih.gamma * tc[1]);
         }
+        r.tangent = xf_vector(in.xf.m, mesh_tangent(m, tri)); // InstancedModelList.cpp:131
     } else {
         r.prim = RTGPU_INVALID_ID;
         objN = ih.objNormal;
@@ -1105,6 +1124,36 @@ inline bool area_light_hit(const rtgpu_area_light& L, V3 o, V3 d, double& t)
     return tri_intersect(o, d, mk(L.a), mk(L.b), mk(L.c), be, ga, t);
 }
 
+// Texture::get, material/Texture.h:24-33 (an index equal to the size is clamped; the reference would read past the image)
+RGBf texture_get(const orc_scene::Tex& T, float x, float y)
+{
+    unsigned px = (unsigned)(x * T.width), py = (unsigned)(y * T.height);
+    px = std::min(px, T.width - 1);
+    py = std::min(py, T.height - 1);
+    size_t offset = ((size_t)py * T.width + px) * 4;
+    RGBf color{(float)T.rgba[offset] / 255.0f, (float)T.rgba[offset + 1] / 255.0f, (float)T.rgba[offset + 2] / 255.0f};
+    return RGBf{(float)std::pow(color.r, T.gamma), (float)std::pow(color.g, T.gamma), (float)std::pow(color.b, T.gamma)}; // RGB::pow(double)
+}
+
+// sample_normal_map, material/NormalMapSampler.h:7-21 with Transformation::tangentToObject (math/Transformation.cpp:132-145)
+V3 sample_normal_map(const orc_scene& S, const SceneHit& hit, uint32_t texture)
+{
+    float x = fmodf(hit.u, 1.0f), y = fmodf(hit.v, 1.0f);
+    if (x < 0) x = 1.0f + x;
+    if (y < 0) y = 1.0f + y;
+    RGBf c = texture_get(S.textures[texture], x, y);
+    V3 nts{2.0f * (c.r - 0.5f), 2.0f * (c.g - 0.5f), 2.0f * (c.b - 0.5f)};
+    V3 tangent = normalized(hit.tangent), normal = normalized(hit.normal);
+    V3 bit = cross(normal, tangent);
+    double M[16] = {tangent.x, bit.x, normal.x, 0, tangent.y, bit.y, normal.y, 0, tangent.z, bit.z, normal.z, 0, 0, 0, 0, 1};
+    return normalized(xf_vector(M, nts));
+}
+// the normal a diffuse / glossy closure shades with (DiffuseMaterial.cpp:33-37, 169-173; GlossyMaterial.cpp:81-85)
+V3 shading_normal(const orc_scene& S, const rtgpu_material& m, const SceneHit& hit)
+{
+    return m.normal_map != 0 ? sample_normal_map(S, hit, m.normal_map - 1) : hit.normal;
+}
+
 // IMaterial::sampleTransport for the supported closures
 void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI, int sampleCount, const RandCtx& rc, int mixLevel, SampleOut& out,
                       int metaIndex = 0, int levelsDeep = 0)
@@ -1208,7 +1257,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         return;
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::sampleTransport, material/DiffuseMaterial.cpp:24-138 (no photon map)
         tn.leafMat = mi;
-        V3 normal = tn.hit.normal;
+        V3 normal = shading_normal(S, m, tn.hit);
         tn.pathTerminationChance = 0.1f;
         tn.isEmissive = false;
         bool useNEE = rc.unit(DIM_NEE_CHOICE) > 0.5f;
@@ -1230,7 +1279,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     case RTGPU_MAT_GLOSSY: { // GlossyMaterial::sampleTransport, material/GlossyMaterial.cpp:68-180
         tn.leafMat = mi;
         V3 hitpoint = tn.hit.hitpoint();
-        V3 normal = tn.hit.normal;
+        V3 normal = shading_normal(S, m, tn.hit);   // meta->normal
         const float roughness = m.roughness;
         bool neeEnabled = roughness > 0;
         bool useNEE = neeEnabled && rc.unit(DIM_NEE_CHOICE) > 0.5;
@@ -1299,17 +1348,6 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     }
 }
 
-// Texture::get, material/Texture.h:24-33 (an index equal to the size is clamped; the reference would read past the image)
-RGBf texture_get(const orc_scene::Tex& T, float x, float y)
-{
-    unsigned px = (unsigned)(x * T.width), py = (unsigned)(y * T.height);
-    px = std::min(px, T.width - 1);
-    py = std::min(py, T.height - 1);
-    size_t offset = ((size_t)py * T.width + px) * 4;
-    RGBf color{(float)T.rgba[offset] / 255.0f, (float)T.rgba[offset + 1] / 255.0f, (float)T.rgba[offset + 2] / 255.0f};
-    return RGBf{(float)std::pow(color.r, T.gamma), (float)std::pow(color.g, T.gamma), (float)std::pow(color.b, T.gamma)}; // RGB::pow(double)
-}
-
 // IMaterial::bsdf for the supported closures
 RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf incoming)
 {
@@ -1326,7 +1364,7 @@ RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf in
     }
     switch (m.type) {
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::bsdf, material/DiffuseMaterial.cpp:140-197
-        double angle = std::max(0.0f, dot(tn.hit.normal, tn.transportDirection));
+        double angle = std::max(0.0f, dot(shading_normal(S, m, tn.hit), tn.transportDirection));
         RGBf value;
         if (tn.isNEERay) {
             RGBf direct = rgb_scale_d(tn.directLighting, angle);

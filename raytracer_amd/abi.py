@@ -36,7 +36,7 @@ class InstanceDesc(C.Structure):
 class Material(C.Structure):
     _fields_ = [("type", C.c_int32), ("color", C.c_float * 3), ("intensity", C.c_double),
                 ("roughness", C.c_float), ("texture", C.c_uint32), ("mix_factor", C.c_double),
-                ("first", C.c_uint32), ("second", C.c_uint32)]
+                ("first", C.c_uint32), ("second", C.c_uint32), ("normal_map", C.c_uint32), ("reserved", C.c_uint32)]
 
 
 class PointLight(C.Structure):
@@ -134,6 +134,7 @@ class MaterialData:
     first: int = 0
     second: int = 0
     texture: Optional[int] = None   # index into SceneData.textures (albedo of a diffuse, emission of an emissive material)
+    normal_map: Optional[int] = None   # index into SceneData.textures (diffuse / glossy)
 
 
 @dataclass
@@ -204,6 +205,7 @@ class PackedScene:
             mats[i].first = int(m.first)
             mats[i].second = int(m.second)
             mats[i].texture = 0 if m.texture is None else int(m.texture) + 1
+            mats[i].normal_map = 0 if m.normal_map is None else int(m.normal_map) + 1
         n_pl = len(scene.point_lights)
         pls = (PointLight * max(1, n_pl))()
         for i, (pos, col, inten) in enumerate(scene.point_lights):

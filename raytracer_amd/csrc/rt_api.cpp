@@ -121,7 +121,13 @@ int validate(const rtgpu_scene_desc* d)
     for (uint32_t i = 0; i < d->n_materials; ++i) {
         const rtgpu_material& m = d->materials[i];
         if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_ADD) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
-        if (m.texture > d->n_textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
+        if (m.texture > d->n_textures || m.normal_map > d->n_textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
+        if (m.normal_map != 0) {
+            // the tangent frame comes from the texture coordinates (shape/TriangleMesh.cpp:130-139); the reference's
+            // fallback for meshes without them (tangent = b - a, texel (0, 0)) is not carried over
+            for (uint32_t k = 0; k < d->n_meshes; ++k)
+                if (!d->meshes[k].texcoords) return fail(RTGPU_ERR_INVALID_ARGUMENT, "normal maps need texture coordinates on every mesh");
+        }
         const bool inner = m.type == RTGPU_MAT_CONSTMIX || m.type == RTGPU_MAT_FRESNELMIX || m.type == RTGPU_MAT_ADD;
         if (inner && (m.first >= d->n_materials || m.second >= d->n_materials))
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix / add material child out of range");
@@ -198,7 +204,7 @@ void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
-                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels};
+                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
     view = rt::SceneView{};
@@ -444,6 +450,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     }
     // ---- materials and lights --------------------------------------------------------------
     std::vector<DevMaterial> mats(desc->n_materials);
+    bool anyNormalMap = false;
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         const rtgpu_material& m = desc->materials[i];
         DevMaterial& dm = mats[i];
@@ -456,6 +463,16 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         dm.intensity = m.intensity;
         dm.texture = m.texture;
         dm.variance = material_variance(*desc, i, 0);
+        dm.normalMap = m.normal_map;
+        dm.pad = 0;
+        if (m.normal_map != 0) anyNormalMap = true;
+    }
+    // object -> world rows of every instance: the tangent of a normal-mapped hit is a world vector
+    // (shape/list/InstancedModelList.cpp:131)
+    std::vector<double> instFwd;
+    if (anyNormalMap) {
+        instFwd.resize((size_t)nInst * 12);
+        for (uint32_t i = 0; i < nInst; ++i) std::memcpy(instFwd.data() + (size_t)i * 12, desc->instances[i].transform, 12 * sizeof(double));
     }
     std::vector<DevTexture> texs(desc->n_textures);
     std::vector<uint32_t> texels;
@@ -517,7 +534,8 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         (rc = upload(vertNormals, &v.vertNormals, bytes)) || (rc = upload(triMat, &v.triMaterial, bytes)) ||
         (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
         (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes)) ||
-        (rc = upload(vertUV, &v.vertUV, bytes)) || (rc = upload(texs, &v.textures, bytes)) || (rc = upload(texels, &v.texels, bytes))) {
+        (rc = upload(vertUV, &v.vertUV, bytes)) || (rc = upload(texs, &v.textures, bytes)) || (rc = upload(texels, &v.texels, bytes)) ||
+        (rc = upload(instFwd, &v.instFwd, bytes))) {
         sc->release();
         delete sc;
         return rc;
@@ -545,6 +563,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         if (desc->materials[i].type == RTGPU_MAT_FRESNELMIX) v.hasFresnelMix = 1;
         if (desc->materials[i].type == RTGPU_MAT_GLASS) v.hasGlass = 1;
         if (desc->materials[i].type == RTGPU_MAT_ADD) v.hasAdd = 1;
+        if (desc->materials[i].normal_map != 0) v.hasNormalMap = 1;
     }
     // ColorEnvironment::getRadiance = color * intensity (RGB * double), ColorEnvironment.cpp:6-9
     for (int a = 0; a < 3; ++a) v.envRadiance[a] = (float)((double)desc->env_color[a] * desc->env_intensity);

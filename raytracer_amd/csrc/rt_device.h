@@ -17,6 +17,8 @@ struct DevMaterial {
     double intensity;
     uint32_t texture;   // 1 + texture index (albedo / emission map), 0 = none
     uint32_t variance;  // IMaterial::hasVariance: 0 no, 1 yes, 2 depends on the hit (a Fresnel mix below decides)
+    uint32_t normalMap; // 1 + texture index of a diffuse / glossy normal map, 0 = none
+    uint32_t pad;
 };
 
 struct DevTexture {
@@ -74,11 +76,13 @@ struct SceneView {
     const float* vertUV;        // per leaf slot: 3 texture coordinates (6 floats), null when no texture is used
     const DevTexture* textures;
     const uint32_t* texels;     // RGBA8 texels of all textures
+    const double* instFwd;      // per instance: rows 0..2 of the object->world matrix; null unless a normal map is used
     uint32_t nMaterials, nPointLights, nAreaLights, nDirLights;
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
     int32_t hasGlass;           // some material is glass: paths carry the extra records of a glass vertex
     int32_t hasAdd;             // some material is an add material: paths carry a collected-emission record
+    int32_t hasNormalMap;
     float envRadiance[3];
 };
 

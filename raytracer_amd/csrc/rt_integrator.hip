@@ -254,7 +254,7 @@ __device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance&
 // ---- shade -----------------------------------------------------------------------------------
 // FIRST: the batch's first pass -- lane q is path q, vertex 0 is its sample's primary hit, and
 // nothing has been written for the path yet.  Otherwise lane q shades path qIn[q].
-// RICH: the scene has glass or add materials (their code and registers are left out otherwise).
+// RICH: the scene has glass or add materials or normal maps (their code and registers are left out otherwise).
 // A path's result is stored when the path ends here (black unless it collected something); a path
 // that goes on through a shadow ray gets black here and its contribution from the shadow stage.
 constexpr int kShadeBlock = RT_SHADE_BLOCK;
@@ -513,6 +513,11 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 }
             } else {
                 if (!sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
+                // the normal a diffuse / glossy closure shades with (DiffuseMaterial.cpp:33-37, GlossyMaterial.cpp:81-85);
+                // Glossy's test of the sampled direction against the surface keeps the hit's own normal (:114)
+                const F3 surfaceNormal = normal;
+                if (RICH && mat.normalMap != 0u && (mat.type == RTGPU_MAT_DIFFUSE || mat.type == RTGPU_MAT_GLOSSY))
+                    normal = sample_normal_map(sv, mat.normalMap - 1u, inst, slot, beta, gamma, normal);
                 if (RICH && mat.type == RTGPU_MAT_GLASS) {
                     // GlassMaterial::sampleTransport up to its traceRay (material/GlassMaterial.cpp:21-107)
                     const F3 objToIncoming = -d;
@@ -685,7 +690,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         done = true;
                         completed = true;   // a direction below the surface ends the path as an emissive black vertex (GlossyMaterial.cpp:117-122)
                         result = rgb_mul(thr, addE);
-                        if (!(dot3(sampleDir, normal) < 0)) {
+                        if (!(dot3(sampleDir, surfaceNormal) < 0)) {
                             if ((RICH && sv.hasAdd)) { pend = rgb_mul(thr, addE); writePend = true; }
                             thr = rgb_mul(thr, color);
                             o = hitpoint + (sampleDir * 0.001f);
@@ -920,7 +925,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
-        const bool rich = sv.hasGlass || sv.hasAdd;
+        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
             Batch batch;

@@ -285,6 +285,43 @@ __device__ __forceinline__ RGBf emission_lookup(const SceneView& sv, uint32_t te
     return texture_get(sv, texture, fabsf(fmodf(u, 1.0f)), fabsf(fmodf(v, 1.0f)));
 }
 
+// sample_normal_map (material/NormalMapSampler.h:7-21) at a triangle hit.  The hit's tangent is row 0 of
+// uvMat^-1 * deltaPosMat (shape/TriangleMesh.cpp:130-139; 2x2 inverse = adjugate / determinant), taken to
+// world space as a vector (shape/list/InstancedModelList.cpp:131); tangentToObject (math/Transformation.cpp:
+// 132-145) builds the frame (tangent, normal x tangent, normal) from the normalised tangent and normal.
+// A sphere has no tangent in the reference (shape/Sphere.cpp:56 leaves it unset): zero here.
+__device__ __forceinline__ F3 sample_normal_map(const SceneView& sv, uint32_t texture, uint32_t inst, uint32_t slot, float beta, float gamma, F3 normal)
+{
+    F3 tangent = f3(0.0f, 0.0f, 0.0f);
+    float u = 0.0f, v = 0.0f;
+    if (slot != kInvalid) {
+        hit_texcoord(sv, slot, beta, gamma, u, v);
+        const float4 r1 = sv.tris[(size_t)slot * 3 + 1], r2 = sv.tris[(size_t)slot * 3 + 2];
+        const F3 d0 = f3(-r1.x, -r1.y, -r1.z), d1 = f3(-r2.x, -r2.y, -r2.z);   // b - a, c - a (the records hold a - b, a - c)
+        const float* t = sv.vertUV + (size_t)slot * 6;
+        const float m00 = t[2] - t[0], m01 = t[3] - t[1], m10 = t[4] - t[0], m11 = t[5] - t[1];
+        const float det = (m00 * m11) - (m10 * m01);
+        const float invdet = 1.0f / det;
+        const float i00 = m11 * invdet, i01 = -m01 * invdet;
+        const F3 ot = f3((i00 * d0.x) + (i01 * d1.x), (i00 * d0.y) + (i01 * d1.y), (i00 * d0.z) + (i01 * d1.z));
+        const double* m = sv.instFwd + (size_t)inst * 12;
+        const double x = ot.x, y = ot.y, z = ot.z;
+        tangent = f3((float)(((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 0.0), (float)(((m[4] * x + m[5] * y) + m[6] * z) + m[7] * 0.0),
+                     (float)(((m[8] * x + m[9] * y) + m[10] * z) + m[11] * 0.0));
+    }
+    float x = fmodf(u, 1.0f), y = fmodf(v, 1.0f);
+    if (x < 0) x = 1.0f + x;
+    if (y < 0) y = 1.0f + y;
+    const RGBf c = texture_get(sv, texture, x, y);
+    const double nx = 2.0f * (c.r - 0.5f), ny = 2.0f * (c.g - 0.5f), nz = 2.0f * (c.b - 0.5f);
+    const F3 T = normalized3(tangent), N = normalized3(normal);
+    const F3 B = cross3(N, T);
+    const F3 mapped = f3((float)((((double)T.x * nx + (double)B.x * ny) + (double)N.x * nz) + 0.0),
+                         (float)((((double)T.y * nx + (double)B.y * ny) + (double)N.y * nz) + 0.0),
+                         (float)((((double)T.z * nx + (double)B.z * ny) + (double)N.z * nz) + 0.0));
+    return normalized3(mapped);
+}
+
 // FresnelMixMaterial::calcMixFactor, material/FresnelMixMaterial.cpp:3-41: unpolarised Fresnel
 // reflectance of the hit for index of refraction `ior` against air, 1 on total internal reflection.
 __device__ __forceinline__ float fresnel_mix_factor(F3 normal, F3 incomingDir, float ior)

@@ -479,9 +479,11 @@ def sun_scene(lights="sun+point"):
     return sc, cam_m, 0.8
 
 
-def textured_scene(seed=3):
+def textured_scene(seed=3, normal_maps=False):
     """The box of box_scene with an albedo map on the floor and the back wall (texture coordinates beyond
-    [0, 1) and negative ones included), a gamma-corrected map on one sphere and an emission map on a small panel."""
+    [0, 1) and negative ones included), a gamma-corrected map on one sphere and an emission map on a small panel.
+    normal_maps: a bump pattern perturbs the shading normal of the floor (diffuse, with its albedo map), of the
+    first sphere (rough glossy) and of the right wall (mirror)."""
     rng = np.random.RandomState(seed)
     sc, cam_m, yfov = box_scene()
     mesh = sc.meshes[0]
@@ -498,14 +500,28 @@ def textured_scene(seed=3):
     stripes[:, 1::2] = (40, 60, 200, 255)
     glow = rng.randint(0, 256, size=(3, 5, 4)).astype(np.uint8)
     sc.textures = [(checker, 1.0), (stripes, 2.2), (glow, 1.0)]
-    sc.materials += [MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=0), MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=1),
-                     MaterialData(MAT_EMISSIVE, (1.0, 1.0, 1.0), intensity=1.5, texture=2)]
+    bump = None
+    if normal_maps:
+        bumps = np.empty((16, 16, 4), np.uint8)
+        bumps[..., 0] = rng.randint(70, 186, size=(16, 16))
+        bumps[..., 1] = rng.randint(70, 186, size=(16, 16))
+        bumps[..., 2] = rng.randint(200, 256, size=(16, 16))
+        bumps[..., 3] = 255
+        sc.textures.append((bumps, 1.0))
+        bump = 3
+    sc.materials += [MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=0, normal_map=bump), MaterialData(MAT_DIFFUSE, (1.0, 1.0, 1.0), texture=1),
+                     MaterialData(MAT_EMISSIVE, (1.0, 1.0, 1.0), intensity=1.5, texture=2),
+                     MaterialData(MAT_GLOSSY, (0.9, 0.9, 0.9), roughness=0.25, normal_map=bump),
+                     MaterialData(MAT_GLOSSY, (0.95, 0.95, 0.95), roughness=0.0, normal_map=bump)]
     tm = mesh.tri_material.copy()
     quad = 2 * 6 * 6
     tm[0:quad] = base            # floor
     tm[2 * quad:3 * quad] = base  # back wall
     nsph = (len(tm) - 6 * quad) // 2
     tm[6 * quad + nsph:] = base + 1   # second sphere
+    if normal_maps:
+        tm[6 * quad:6 * quad + nsph] = base + 3   # first sphere
+        tm[5 * quad:6 * quad] = base + 4          # right wall
     nv = len(mesh.vertices)
     sc.meshes = [MeshData(np.concatenate([mesh.vertices, panel_v]), np.concatenate([mesh.normals, vertex_normals(panel_v, panel_f)]),
                           np.concatenate([mesh.indices, panel_f + np.uint32(nv)]),
