@@ -1,0 +1,108 @@
+// render_glb.cpp -- the render branch of the reference's executable (raytracer/src/exe/Raytracer.cpp:52-341)
+// over the GPU path: the same option names for what this library covers, loadGLTFScene + build replaced by
+// rtgpu_gltf_load + rtgpu_scene_create, Renderer::render replaced by the adapter's GpuRenderer::render.
+//
+//   render_glb --scene scene.glb --width 500 --height 500 [--xstart .. --ystart .. --xend .. --yend ..]
+//              [--soupify] [--aageometry 4] [--aamaterial 4] [--seed 0] [--outputtype ppm|tile] [--output output]
+//
+// Output: "tile" = the TILE exchange file of io/TileFile.cpp:8-27, "ppm" = the text PPM of io/PPMFile.cpp:4-24.
+// (exr / png output, photon mapping, tile merging and the preview window stay with the reference's executable.)
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "rtgpu_adapter.hpp"
+
+namespace {
+
+// write_to_tile_file, io/TileFile.cpp:8-27
+void writeTile(const std::vector<float>& pixels, int width, int height, const rtgpu::Tile& tile, const std::string& path)
+{
+    std::ofstream out(path, std::ios::out | std::ios::trunc | std::ios::binary);
+    out.write("TILE", 4);
+    const int res[2] = {width, height};
+    out.write(reinterpret_cast<const char*>(res), sizeof(res));
+    out.write(reinterpret_cast<const char*>(&tile), sizeof(tile));
+    for (int y = tile.yStart; y < tile.yEnd; ++y)
+        out.write(reinterpret_cast<const char*>(&pixels[3 * ((size_t)y * width + tile.xStart)]), sizeof(float) * 3 * (tile.xEnd - tile.xStart));
+}
+
+// write_to_ppm, io/PPMFile.cpp:4-24
+void writePpm(const std::vector<float>& pixels, int width, int height, const std::string& path)
+{
+    std::ofstream out(path, std::ios::out | std::ios::trunc);
+    out << "P3" << std::endl << width << " " << height << std::endl << 255 << std::endl;
+    for (int y = 0; y < height; ++y) {
+        for (int x = 0; x < width; ++x) {
+            const float* p = &pixels[3 * ((size_t)y * width + x)];
+            out << static_cast<int>(p[0] * 255) << " " << static_cast<int>(p[1] * 255) << " " << static_cast<int>(p[2] * 255) << " ";
+        }
+        out << std::endl;
+    }
+}
+
+} // namespace
+
+int main(int argc, char** argv)
+{
+    std::map<std::string, std::string> opt = {{"scene", "scene.glb"}, {"width", "500"}, {"height", "500"}, {"xstart", "0"}, {"ystart", "0"},
+                                              {"outputtype", "tile"}, {"output", "output"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"}};
+    bool soupify = false;
+    for (int i = 1; i < argc; ++i) {
+        std::string a = argv[i];
+        if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "unexpected argument %s\n", argv[i]); return -1; }
+        a = a.substr(2);
+        if (a == "soupify") { soupify = true; continue; }
+        if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output\n"); return 0; }
+        if (i + 1 >= argc) { std::fprintf(stderr, "option --%s needs a value\n", a.c_str()); return -1; }
+        opt[a] = argv[++i];
+    }
+    const int width = std::atoi(opt["width"].c_str()), height = std::atoi(opt["height"].c_str());
+    if (width <= 0 || height <= 0) { std::fprintf(stderr, "Invalid frame size.\n"); return -1; }
+    const int xstart = std::atoi(opt["xstart"].c_str()), ystart = std::atoi(opt["ystart"].c_str());
+    const int xend = opt.count("xend") ? std::atoi(opt["xend"].c_str()) : (width - xstart);   // exe/Raytracer.cpp:113-114
+    const int yend = opt.count("yend") ? std::atoi(opt["yend"].c_str()) : (height - ystart);
+    if (xstart >= xend || xstart >= width || xend > width || xstart < 0 || xend < 0) { std::fprintf(stderr, "Invalid xstart or xend.\n"); return -1; }
+    if (ystart >= yend || ystart >= height || yend > height || ystart < 0 || yend <= 0) { std::fprintf(stderr, "Invalid ystart or yend.\n"); return -1; }
+    rtgpu::RenderSettings settings;
+    settings.geometryAAModifier = std::atoi(opt["aageometry"].c_str());
+    settings.materialAAModifier = std::atoi(opt["aamaterial"].c_str());
+    settings.seed = (uint32_t)std::strtoul(opt["seed"].c_str(), nullptr, 10);
+    if (settings.geometryAAModifier <= 0 || settings.materialAAModifier <= 0) { std::fprintf(stderr, "Invalid AA settings!\n"); return -1; }
+    const std::string type = opt["outputtype"];
+    if (type != "tile" && type != "ppm") { std::fprintf(stderr, "Unknown output type (this build writes tile and ppm).\n"); return -1; }
+
+    rtgpu_gltf* file = nullptr;
+    try {
+        std::printf("Loading scene.\n");
+        rtgpu::check(rtgpu_gltf_load(opt["scene"].c_str(), static_cast<float>(width) / height, soupify ? 1 : 0, &file));
+        rtgpu_camera camera;
+        rtgpu::check(rtgpu_gltf_camera(file, &camera));          // Renderer::findCamera: "No camera in scene."
+        rtgpu::GpuScene scene(*rtgpu_gltf_scene_desc(file));     // DynamicScene::build
+        rtgpu_gltf_free(file);
+        file = nullptr;
+        rtgpu::GpuRenderer renderer(scene, camera);
+        std::vector<float> pixels((size_t)width * height * 3, 0.0f);
+        const rtgpu::Tile tile{xstart, ystart, xend, yend};
+        const rtgpu_render_stats stats = renderer.render(pixels.data(), width, height, tile, settings,
+            [](const std::string& job, float progress, bool done) {
+                std::printf("%s - %g%%\r", job.c_str(), progress * 100);
+                if (done) std::printf("\n");
+                std::fflush(stdout);
+            });
+        std::printf("Render done in %.3f milliseconds on the device.\n", stats.device_ms);
+        std::printf("rays: primary %llu extension %llu shadow %llu\n", (unsigned long long)stats.primary_rays,
+                    (unsigned long long)stats.extension_rays, (unsigned long long)stats.shadow_rays);
+        if (type == "tile") writeTile(pixels, width, height, tile, opt["output"] + ".tile");
+        else writePpm(pixels, width, height, opt["output"] + ".ppm");
+    } catch (const std::exception& e) {
+        if (file) rtgpu_gltf_free(file);
+        std::fprintf(stderr, "%s\n", e.what());
+        return -1;
+    }
+    return 0;
+}

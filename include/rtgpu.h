@@ -40,7 +40,11 @@ typedef enum rtgpu_status {
     RTGPU_ERR_HIP = 3,              /* a HIP call failed; message holds hipGetErrorString */
     RTGPU_ERR_OUT_OF_MEMORY = 4,
     RTGPU_ERR_NO_CAMERA = 5,        /* std::runtime_error("No camera in scene.") renderer/Renderer.cpp:318 */
-    RTGPU_ERR_LIMIT = 6             /* a documented size limit of an entry point was exceeded */
+    RTGPU_ERR_LIMIT = 6,            /* a documented size limit of an entry point was exceeded */
+    RTGPU_ERR_IO = 7,               /* std::runtime_error("Failed to load gltf") io/GLTF.cpp:676-678 and the loader's other
+                                     * complaints about a file's content */
+    RTGPU_ERR_UNSUPPORTED = 8       /* std::runtime_error("Unsupported ...") of the loader (io/GLTF.cpp:62,82,91,204,233), and
+                                     * file features this library has no decoder for (JPEG, HDR maps) */
 } rtgpu_status;
 
 /* ---- scene description (flat arrays; replaces the DynamicScene graph) ---------------- */
@@ -282,6 +286,25 @@ int rtgpu_scene_get_info(const rtgpu_scene* scene, rtgpu_scene_info* out);
  * somewhat more boxes than this (subtrees taken over by idle lanes are entered early). */
 int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
                                      uint64_t n, uint32_t* d_counts, void* hip_stream);
+
+/* ---- scene ingestion ------------------------------------------------------------------- */
+
+/* A binary glTF file flattened into a scene description in host memory: loadGLTFScene (io/GLTF.cpp:682-705:
+ * LoadBinaryFromFile, then nodes / primitives / materials / lights / cameras of the default scene) followed by
+ * the flattening of DynamicScene::build (scene/dynamic/DynamicScene.cpp:108-145), or of soupifyScene (:17-106,
+ * the reference's --soupify: one world-space mesh, per-triangle materials) when `soupify` is non-zero.
+ * image_aspect_ratio = width / height of the frame, as loadGLTFScene takes it (the camera's x field of view
+ * follows from the file's yfov).  PNG images only; no GPU is touched. */
+typedef struct rtgpu_gltf rtgpu_gltf;
+int rtgpu_gltf_load(const char* glb_path, float image_aspect_ratio, int soupify, rtgpu_gltf** out);
+/* The description to hand to rtgpu_scene_create; its arrays live until rtgpu_gltf_free. */
+const rtgpu_scene_desc* rtgpu_gltf_scene_desc(const rtgpu_gltf* g);
+/* Renderer::findCamera (renderer/Renderer.cpp:304-320): the last camera whose node (or parent) carries
+ * IsMainCamera, else the first; RTGPU_ERR_NO_CAMERA without one.  Thin-lens parameters from the node's
+ * FocalDistance / Aperture / FStop / SensorSize (io/GLTF.cpp:598-629). */
+int rtgpu_gltf_camera(const rtgpu_gltf* g, rtgpu_camera* out);
+uint32_t rtgpu_gltf_camera_count(const rtgpu_gltf* g);
+void rtgpu_gltf_free(rtgpu_gltf* g);
 
 #ifdef __cplusplus
 }

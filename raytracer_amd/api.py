@@ -26,6 +26,7 @@ EXPORTS = [
     "rtgpu_trace_closest", "rtgpu_trace_closest_device", "rtgpu_trace_any", "rtgpu_trace_any_device",
     "rtgpu_generate_primary_device", "rtgpu_render", "rtgpu_render_device", "rtgpu_camera_from_transform",
     "rtgpu_scene_get_info", "rtgpu_trace_closest_count_device",
+    "rtgpu_gltf_load", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
 ]
 
 _lib = None
@@ -121,12 +122,16 @@ def _stream_ptr(stream):
 class Scene:
     """A built, GPU-resident scene (the reference's Scene after DynamicScene::build)."""
 
-    def __init__(self, scene: abi.SceneData):
-        self._packed = abi.PackedScene(scene)
+    def __init__(self, scene):
+        """scene: abi.SceneData, or an abi.SceneDesc whose arrays the caller keeps alive during this call
+        (e.g. gltf.GltfScene.desc)."""
         h = C.c_void_p()
-        _check(lib().rtgpu_scene_create(C.byref(self._packed.desc), C.byref(h)))
+        if isinstance(scene, abi.SceneDesc):
+            _check(lib().rtgpu_scene_create(C.byref(scene), C.byref(h)))
+        else:
+            packed = abi.PackedScene(scene)
+            _check(lib().rtgpu_scene_create(C.byref(packed.desc), C.byref(h)))  # the library copies everything it needs
         self._h = h
-        self._packed = None  # the library copied everything it needs
 
     def close(self):
         if getattr(self, "_h", None):

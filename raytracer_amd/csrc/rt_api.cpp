@@ -200,6 +200,10 @@ int ceil_log2(uint32_t n)
 
 } // namespace
 
+namespace rt {
+int set_error(int code, const std::string& msg) { return fail(code, msg); }
+} // namespace rt
+
 void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);

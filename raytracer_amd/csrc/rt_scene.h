@@ -16,6 +16,9 @@ struct rtgpu_scene {
 
 namespace rt {
 
+// Stores the calling thread's error message (rtgpu_last_error) and returns `code`.
+int set_error(int code, const std::string& msg);
+
 // Fills normal and area of an area light (AreaLight::getNormal / getSurfaceArea, light/AreaLight.cpp:43-53).
 void area_light_derived(DevAreaLight& l);
 

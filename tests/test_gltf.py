@@ -1,0 +1,326 @@
+"""The .glb -> rtgpu_scene_desc bridge (host code of the library; no GPU needed).
+
+What loadGLTFScene + DynamicScene::build / soupifyScene produce for a file (raytracer/src/lib/io/GLTF.cpp,
+scene/dynamic/DynamicScene.cpp) is checked field by field on files written by `gltf.GlbBuilder`: the reference
+ships no glTF assets and its loader (tinygltf) is not built here, so the expected values are derived from the
+loader's source, cited per assertion.
+"""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+import oracle
+from raytracer_amd import abi, api, gltf, scenes
+
+
+def _quad(z=0.0):
+    v = np.array([[-1, -1, z], [1, -1, z], [1, 1, z], [-1, 1, z]], np.float32)
+    n = np.tile(np.array([[0, 0, 1]], np.float32), (4, 1))
+    uv = np.array([[0, 0], [1, 0], [1, 1], [0, 1]], np.float32)
+    return v, n, np.array([[0, 1, 2], [0, 2, 3]], np.uint32), uv
+
+
+def _full_scene(tmp_path):
+    b = gltf.GlbBuilder()
+    rng = np.random.RandomState(0)
+    albedo = rng.randint(0, 256, size=(4, 8, 4)).astype(np.uint8)
+    bumps = rng.randint(100, 156, size=(2, 2, 4)).astype(np.uint8)
+    t_albedo, t_bumps = b.add_texture(albedo), b.add_texture(bumps)
+    m_plain = b.add_material(pbrMetallicRoughness={"baseColorFactor": [0.5, 0.25, 0.125, 1.0]})
+    m_rich = b.add_material(pbrMetallicRoughness={"baseColorFactor": [0.9, 0.8, 0.7, 1.0], "metallicFactor": 0.25, "roughnessFactor": 0.3,
+                                                  "baseColorTexture": {"index": t_albedo}},
+                            normalTexture={"index": t_bumps}, emissiveFactor=[0.1, 0.2, 0.3])
+    v, n, idx, uv = _quad()
+    us = scenes.uv_sphere(8, 4)
+    mesh_quad = b.add_primitive_mesh([(v, n, idx, uv, m_rich)])
+    mesh_two = b.add_primitive_mesh([(us.vertices, us.normals, us.indices, None, m_plain), (v, n, idx, None, None)])
+    root = b.add_node(translation=[1.0, 2.0, 3.0], rotation=[0.0, 0.38268343, 0.0, 0.92387953], scale=[2.0, 2.0, 2.0],
+                      extras={"IsMainCamera": 1, "FocalDistance": 4.0, "FStop": 2.8})
+    b.add_node(parent=root, mesh=mesh_quad, translation=[0.0, 0.5, 0.0],
+               extras={"Material.ClearCoat": True, "Material.ClearCoatIOR": 1.6, "Material.ClearCoatRoughness": 0.05,
+                       "Material.Transmission": 0.4, "Material.IOR": 1.33, "Material.AttenuationStrength": 3,
+                       "Material.EmissionStrength": 2.5, "Material.Alpha": 0.75})
+    b.add_node(mesh=mesh_quad, translation=[5.0, 0.0, 0.0])      # the same mesh again: one shape, two instances
+    b.add_node(mesh=mesh_two, matrix=[1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, -3, 0, 1, 1])   # column-major: rotation about x + translation
+    b.add_node(parent=root, camera=b.add_camera(0.6))
+    b.add_node(camera=b.add_camera(0.9), translation=[0.0, 0.0, 9.0])
+    b.add_node(translation=[0.0, 4.0, 0.0], extras={"IsPointLight": True, "LightIntensity": 120.0, "LightColor": [1.0, 0.5, 0.25]})
+    b.add_node(extras={"IsPointLight": True, "LightIntensity": 0.0})   # dropped: intensity < 1e-6 (io/GLTF.cpp:547-550)
+    tri_v = np.array([[0, 0, 0], [1, 0, 0], [0, 0, 1]], np.float32)
+    tri = b.add_primitive_mesh([(tri_v, np.tile(np.array([[0, -1, 0]], np.float32), (3, 1)), np.array([[0, 1, 2]]), None, None)])
+    b.add_node(mesh=tri, translation=[0.0, 6.0, 0.0], scale=[2.0, 1.0, 2.0], extras={"IsAreaLight": True})
+    b.add_node(rotation=[0.70710678, 0.0, 0.0, 0.70710678], extras={"IsDirectionalLight": True, "LightIntensity": 3, "DirectionalLight.Angle": 0.02})
+    b.set_scene_extras(EnvironmentIntensity=0.5, EnvironmentColor=[0.2, 0.3, 0.4])
+    path = os.path.join(tmp_path, "scene.glb")
+    b.write(path)
+    return path, albedo, bumps
+
+
+def test_nodes_materials_lights_and_camera_of_a_file(tmp_path):
+    path, albedo, bumps = _full_scene(str(tmp_path))
+    with gltf.load_glb(path, image_aspect_ratio=16 / 9) as g:
+        sc = g.scene_data()
+        cam = g.camera()
+        assert g.camera_count() == 2
+    # ---- instances: one per (node, primitive), transforms accumulated parent * child (DynamicScene.cpp:118) ----
+    assert len(sc.meshes) == 3 and [i.shape for i in sc.instances] == [0, 0, 1, 2]   # meshCache: the quad is stored once
+    root_m, root_inv = scenes.trs((1.0, 2.0, 3.0), (0.0, 0.38268343, 0.0, 0.92387953), (2.0, 2.0, 2.0))
+    want = root_m @ scenes.translate(0.0, 0.5, 0.0)
+    assert np.allclose(sc.instances[0].transform, want, atol=1e-12)
+    assert np.allclose(sc.instances[0].inverse @ want, np.eye(4), atol=1e-12)
+    assert np.allclose(sc.instances[1].transform, scenes.translate(5.0, 0.0, 0.0))
+    col_major = np.array([1, 0, 0, 0, 0, 0, 1, 0, 0, -1, 0, 0, -3, 0, 1, 1], float).reshape(4, 4).T
+    assert np.allclose(sc.instances[2].transform, col_major) and np.allclose(sc.instances[3].transform, col_major)
+    assert np.allclose(sc.instances[2].inverse @ col_major, np.eye(4), atol=1e-12)
+    assert sc.meshes[0].texcoords is not None and sc.meshes[1].texcoords is None
+    assert sc.meshes[1].indices.shape == (scenes.uv_sphere(8, 4).indices.shape[0], 3)
+
+    # ---- the material tree of loadMaterial (io/GLTF.cpp:323-455), outermost first ----
+    M = sc.materials
+    top = M[sc.instances[0].material]
+    assert top.type == abi.MAT_CONSTMIX and top.mix_factor == 0.75 and M[top.first].type == abi.MAT_TRANSPARENT          # :444-452 alpha
+    add = M[top.second]
+    assert add.type == abi.MAT_ADD                                                                                      # :435-441
+    em = M[add.first]
+    assert em.type == abi.MAT_EMISSIVE and np.allclose(em.color, (0.1, 0.2, 0.3)) and em.intensity == 2.5               # :426-433
+    trans = M[add.second]
+    assert trans.type == abi.MAT_CONSTMIX and trans.mix_factor == 0.4                                                   # :399-410
+    glass = M[trans.second]
+    assert glass.type == abi.MAT_GLASS and glass.intensity == 1.33 and glass.roughness == 3.0 and np.allclose(glass.color, (0.9, 0.8, 0.7))
+    coat = M[trans.first]
+    assert coat.type == abi.MAT_FRESNELMIX and np.isclose(coat.roughness, 1.6)                                          # :349-360
+    coat_glossy = M[coat.second]
+    assert coat_glossy.type == abi.MAT_GLOSSY and np.isclose(coat_glossy.roughness, 0.05) and coat_glossy.normal_map is not None
+    metal = M[coat.first]
+    assert metal.type == abi.MAT_CONSTMIX and metal.mix_factor == 0.25                                                  # :335-346
+    diffuse, glossy = M[metal.first], M[metal.second]
+    assert diffuse.type == abi.MAT_DIFFUSE and np.allclose(diffuse.color, (0.9, 0.8, 0.7)) and diffuse.intensity == 1.0
+    assert glossy.type == abi.MAT_GLOSSY and np.isclose(glossy.roughness, 0.3) and np.allclose(glossy.color, (0.9, 0.8, 0.7))
+    assert diffuse.texture is not None and diffuse.normal_map == glossy.normal_map == coat_glossy.normal_map
+    px, gamma = sc.textures[diffuse.texture]
+    assert gamma == 2.2 and np.array_equal(px, albedo)                                                                  # :362-369
+    px, gamma = sc.textures[diffuse.normal_map]
+    assert gamma == 1.0 and np.array_equal(px, bumps)
+    # materialCache (:473-493): the second user of the material gets the tree built with the first node's extras
+    assert sc.instances[1].material == sc.instances[0].material
+    plain = M[sc.instances[2].material]
+    assert plain.type == abi.MAT_DIFFUSE and np.allclose(plain.color, (0.5, 0.25, 0.125)) and plain.texture is None
+    dflt = M[sc.instances[3].material]
+    assert dflt.type == abi.MAT_DIFFUSE and np.allclose(dflt.color, (1, 1, 1)) and dflt.intensity == 0.8                # :481-486
+
+    # ---- lights (io/GLTF.cpp:517-561, applyTransform of light/*.cpp) ----
+    assert len(sc.point_lights) == 1
+    pos, col, inten = sc.point_lights[0]
+    assert np.allclose(pos, (0, 4, 0)) and np.allclose(col, (1.0, 0.5, 0.25)) and inten == 120.0
+    (a, bb, c, col, inten), = sc.area_lights
+    assert np.allclose(a, (0, 6, 0)) and np.allclose(bb, (2, 6, 0)) and np.allclose(c, (0, 6, 2)) and inten == 500 and np.allclose(col, 1)
+    (d, angle, col, inten), = sc.directional_lights
+    assert np.allclose(d, (0, 0, -1), atol=1e-6) and np.isclose(angle, 0.01) and inten == 3.0   # (0,-1,0) turned 90 degrees about x
+    assert sc.env is not None and np.allclose(sc.env[0], (0.2, 0.3, 0.4)) and sc.env[1] == 0.5   # :650-680
+
+    # ---- camera: the one under the IsMainCamera node wins over the first-listed... both are listed; main is the child ----
+    x_fov = np.degrees(2 * np.arctan(np.tan(0.6 / 2) * 16 / 9))                                 # :585-587
+    ref = api.camera_from_transform(x_fov, root_m)
+    for f in ("origin", "u", "v", "w"):
+        assert np.allclose(getattr(cam, f)[:], getattr(ref, f)[:], atol=1e-6)
+    assert np.isclose(cam.width, ref.width) and cam.focal_distance == 4.0
+    dist_to_sensor = 0.5 * 0.036 / np.tan(0.5 * np.radians(x_fov))
+    assert np.isclose(cam.aperture, 0.5 * (1.0 / (1.0 / 4.0 + 1.0 / dist_to_sensor)) / 2.8)       # :612-625 (FStop on the parent)
+
+
+def test_soupify_merges_instances_in_world_space(tmp_path):
+    """--soupify (DynamicScene::soupifyScene, scene/dynamic/DynamicScene.cpp:17-106): one mesh, vertices moved to
+    world space, per-triangle materials; rays find the same surfaces at the same distances as in the instanced scene."""
+    path, _, _ = _full_scene(str(tmp_path))
+    with gltf.load_glb(path, 1.0) as g, gltf.load_glb(path, 1.0, soupify=True) as s:
+        inst, soup = g.scene_data(), s.scene_data()
+    assert len(soup.meshes) == 1 and len(soup.instances) == 1 and np.allclose(soup.instances[0].transform, np.eye(4))
+    n_tris = [inst.meshes[i.shape].indices.shape[0] for i in inst.instances]
+    assert soup.meshes[0].indices.shape[0] == sum(n_tris)
+    want_mat = np.concatenate([np.full(n, i.material, np.uint32) for n, i in zip(n_tris, inst.instances)])
+    assert np.array_equal(soup.meshes[0].tri_material, want_mat)                                  # CompositeMaterial ranges, :67-71
+    v0 = inst.meshes[0].vertices
+    moved = (np.asarray(inst.instances[0].transform) @ np.c_[v0, np.ones(len(v0))].T).T[:, :3]
+    assert np.allclose(soup.meshes[0].vertices[:len(v0)], moved, atol=1e-5)
+    o, d = scenes.random_rays(20000, (-6, -3, -6), (8, 6, 8), seed=5)
+    a = oracle.OracleScene(inst).trace_closest(o, d)
+    b = oracle.OracleScene(soup).trace_closest(o, d)
+    hit = a["inst"] != abi.INVALID_ID
+    assert hit.sum() > 200 and np.array_equal(hit, b["inst"] != abi.INVALID_ID)
+    assert np.allclose(a["t"][hit], b["t"][hit], rtol=2e-4)
+
+
+def test_loader_errors(tmp_path):
+    p = str(tmp_path)
+    with pytest.raises(api.RtgpuError, match="cannot open"):
+        gltf.load_glb(os.path.join(p, "missing.glb"))
+    bad = os.path.join(p, "bad.glb")
+    open(bad, "wb").write(b"not a glb file at all....")
+    with pytest.raises(api.RtgpuError, match="rtgpu error 7"):
+        gltf.load_glb(bad)
+    # no camera: Renderer::findCamera throws (renderer/Renderer.cpp:316-318)
+    b = gltf.GlbBuilder()
+    v, n, idx, uv = _quad()
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, None, None)]))
+    b.write(os.path.join(p, "nocam.glb"))
+    with gltf.load_glb(os.path.join(p, "nocam.glb")) as g:
+        with pytest.raises(api.RtgpuError, match="No camera in scene."):
+            g.camera()
+    # implicit normals (io/GLTF.cpp:231-234)
+    b = gltf.GlbBuilder()
+    m = b.add_primitive_mesh([(v, n, idx, None, None)])
+    del b.doc["meshes"][m]["primitives"][0]["attributes"]["NORMAL"]
+    b.add_node(mesh=m)
+    b.write(os.path.join(p, "nonormals.glb"))
+    with pytest.raises(api.RtgpuError, match="Implicit normals are not supported"):
+        gltf.load_glb(os.path.join(p, "nonormals.glb"))
+    # an area light must be one triangle (:533-536)
+    b = gltf.GlbBuilder()
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, None, None)]), extras={"IsAreaLight": True})
+    b.write(os.path.join(p, "arealight.glb"))
+    with pytest.raises(api.RtgpuError, match="must be triangular"):
+        gltf.load_glb(os.path.join(p, "arealight.glb"))
+    # JPEG data has no decoder here
+    b = gltf.GlbBuilder()
+    b.doc["images"].append({"bufferView": b._view(b"\xff\xd8\xff\xe0" + b"\x00" * 16), "mimeType": "image/jpeg"})
+    b.doc["textures"].append({"source": 0})
+    mat = b.add_material(pbrMetallicRoughness={"baseColorTexture": {"index": 0}})
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, uv, mat)]))
+    b.write(os.path.join(p, "jpeg.glb"))
+    with pytest.raises(api.RtgpuError, match="rtgpu error 8"):
+        gltf.load_glb(os.path.join(p, "jpeg.glb"))
+    # a truncated chunk
+    data = open(os.path.join(p, "nocam.glb"), "rb").read()
+    open(os.path.join(p, "cut.glb"), "wb").write(data[:40] + struct.pack("<I", 1 << 30) + data[44:60])
+    with pytest.raises(api.RtgpuError):
+        gltf.load_glb(os.path.join(p, "cut.glb"))
+
+
+def test_png_round_trip_with_filters(tmp_path):
+    """The PNG reader against zlib-compressed files with every row filter type (written by hand below)."""
+    import zlib
+    rng = np.random.RandomState(3)
+    px = rng.randint(0, 256, size=(5, 7, 4)).astype(np.uint8)
+    rows = []
+    prev = np.zeros(7 * 4, np.int32)
+    for y in range(5):
+        cur = px[y].reshape(-1).astype(np.int32)
+        f = y % 5
+        left = np.concatenate([np.zeros(4, np.int32), cur[:-4]])
+        upleft = np.concatenate([np.zeros(4, np.int32), prev[:-4]])
+        if f == 0: pred = np.zeros_like(cur)
+        elif f == 1: pred = left
+        elif f == 2: pred = prev
+        elif f == 3: pred = (left + prev) // 2
+        else:
+            p = left + prev - upleft
+            pa, pb, pc = np.abs(p - left), np.abs(p - prev), np.abs(p - upleft)
+            pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+        rows.append(bytes([f]) + ((cur - pred) % 256).astype(np.uint8).tobytes())
+        prev = cur
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    comp = zlib.compress(b"".join(rows))
+    png = (b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", 7, 5, 8, 6, 0, 0, 0)) + chunk(b"IDAT", comp[:20]) + chunk(b"IDAT", comp[20:])
+           + chunk(b"IEND", b""))
+    b = gltf.GlbBuilder()
+    b.doc["images"].append({"bufferView": b._view(png), "mimeType": "image/png"})
+    b.doc["textures"].append({"source": 0})
+    v, n, idx, uv = _quad()
+    mat = b.add_material(pbrMetallicRoughness={"baseColorTexture": {"index": 0}})
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, uv, mat)]))
+    path = os.path.join(str(tmp_path), "png.glb")
+    b.write(path)
+    with gltf.load_glb(path) as g:
+        (got, gamma), = g.scene_data().textures
+    assert np.array_equal(got, px) and gamma == 2.2
+
+
+def _render_scene(tmp_path):
+    """A small room exported to .glb: instanced spheres under a scaled parent, textured floor, lights from extras."""
+    b = gltf.GlbBuilder()
+    rng = np.random.RandomState(1)
+    tex = b.add_texture(rng.randint(60, 256, size=(8, 8, 4)).astype(np.uint8))
+    floor_m = b.add_material(pbrMetallicRoughness={"baseColorFactor": [1, 1, 1, 1], "baseColorTexture": {"index": tex}})
+    ball_m = b.add_material(pbrMetallicRoughness={"baseColorFactor": [0.8, 0.3, 0.2, 1], "metallicFactor": 0.5, "roughnessFactor": 0.2})
+    glow_m = b.add_material(pbrMetallicRoughness={"baseColorFactor": [0.2, 0.6, 0.3, 1]}, emissiveFactor=[0.1, 0.3, 0.6])
+    fv, ff = scenes.grid_quad((-3, 0, -3), (0, 0, 6), (6, 0, 0), 3, 3)
+    fv = np.asarray(fv, np.float32); ff = np.asarray(ff, np.uint32)
+    floor = b.add_primitive_mesh([(fv, scenes.vertex_normals(fv, ff), ff, fv[:, [0, 2]] * 0.4, floor_m)])
+    us = scenes.uv_sphere(12, 6)
+    ball = b.add_primitive_mesh([(us.vertices, us.normals, us.indices, None, ball_m)])
+    glow = b.add_primitive_mesh([(us.vertices, us.normals, us.indices, None, glow_m)])
+    b.add_node(mesh=floor)
+    group = b.add_node(translation=[0.0, 0.7, 0.0], scale=[0.7, 0.7, 0.7])
+    b.add_node(parent=group, mesh=ball, translation=[-1.5, 0.0, 0.0])
+    b.add_node(parent=group, mesh=ball, translation=[1.5, 0.0, 0.5], rotation=[0.0, 0.5, 0.0, 0.8660254])
+    b.add_node(parent=group, mesh=glow, translation=[0.0, 0.6, -1.5], scale=[0.6, 0.6, 0.6], extras={"Material.EmissionStrength": 1.5})
+    b.add_node(translation=[1.0, 4.0, 2.0], extras={"IsPointLight": True, "LightIntensity": 150.0})
+    cam_m = scenes.look_at((0.0, 2.2, 5.0), (0.0, 0.6, 0.0))
+    b.add_node(camera=b.add_camera(0.7), matrix=[float(x) for x in np.asarray(cam_m).T.reshape(-1)], extras={"IsMainCamera": True})
+    b.set_scene_extras(EnvironmentIntensity=0.3, EnvironmentColor=[0.5, 0.6, 0.8])
+    path = os.path.join(tmp_path, "room.glb")
+    b.write(path)
+    return path
+
+
+def test_oracle_renders_a_loaded_file(tmp_path):
+    """The flattened description is a complete scene: the oracle renders it, instanced and soupified alike."""
+    path = _render_scene(str(tmp_path))
+    st = abi.make_settings(32, 24, geometry_aa=4, material_aa=4, seed=3)
+    with gltf.load_glb(path, 32 / 24) as g, gltf.load_glb(path, 32 / 24, soupify=True) as s:
+        a, _ = oracle.OracleScene(g.scene_data()).render(g.camera(), st)
+        b, _ = oracle.OracleScene(s.scene_data()).render(s.camera(), st)
+    assert np.isfinite(a).all() and a.mean() > 0.05
+    # same surfaces, same random numbers; normals of the soup are not renormalised after the scale (TriangleMesh.cpp:311-325)
+    assert np.sqrt(np.mean((a - b) ** 2)) / np.sqrt(np.mean(a ** 2)) < 0.05
+
+
+@pytest.mark.gpu
+def test_gpu_renders_a_loaded_file_like_the_oracle(tmp_path):
+    """File -> rtgpu_gltf_load -> rtgpu_scene_create(desc) -> render, against the oracle on the same description."""
+    path = _render_scene(str(tmp_path))
+    st = abi.make_settings(64, 48, geometry_aa=4, material_aa=8, seed=3)
+    for soup in (False, True):
+        with gltf.load_glb(path, 64 / 48, soupify=soup) as g:
+            cam = g.camera()
+            ref, _ = oracle.OracleScene(g.scene_data()).render(cam, st)
+            with api.Scene(g.desc) as scene:
+                img, _ = api.Renderer().render(scene, cam, st)
+        assert np.isfinite(img).all()
+        assert np.sqrt(np.mean((img - ref) ** 2)) / np.sqrt(np.mean(ref ** 2)) <= 1e-4
+
+
+@pytest.mark.gpu
+def test_render_glb_program_follows_the_reference_command_line(tmp_path):
+    """examples/render_glb (the render branch of raytracer/src/exe/Raytracer.cpp with the same option names):
+    a tile of the frame equals the same tile rendered through the Python mirror bit for bit; a file without a
+    camera ends with the reference's message and exit code -1 (exe/Raytracer.cpp:224-226 style)."""
+    import subprocess
+    from raytracer_amd import tilefile
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_glb")
+    if not os.path.exists(exe):
+        pytest.fail("examples/render_glb is missing: build it with `make -C examples`")
+    path = _render_scene(str(tmp_path))
+    out = os.path.join(str(tmp_path), "frame")
+    run = subprocess.run([exe, "--scene", path, "--width", "64", "--height", "48", "--xstart", "8", "--ystart", "4", "--xend", "56", "--yend", "40",
+                          "--aageometry", "4", "--aamaterial", "4", "--seed", "9", "--outputtype", "tile", "--output", out],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert "Loading scene." in run.stdout and "rays: primary 6912" in run.stdout   # 48 x 36 pixels x 4
+    w, h, tile, px = tilefile.read_tile_file(out + ".tile")
+    assert (w, h, tile) == (64, 48, (8, 4, 56, 40))
+    st = abi.make_settings(64, 48, geometry_aa=4, material_aa=4, seed=9, tile=(8, 4, 56, 40))
+    with gltf.load_glb(path, 64 / 48) as g:
+        with api.Scene(g.desc) as scene:
+            img, _ = api.Renderer().render(scene, g.camera(), st)
+    assert np.array_equal(px, img[4:40, 8:56]) and px.mean() > 0.05
+    b = gltf.GlbBuilder()
+    v, n, idx, uv = _quad()
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, None, None)]))
+    b.write(os.path.join(str(tmp_path), "nocam.glb"))
+    run = subprocess.run([exe, "--scene", os.path.join(str(tmp_path), "nocam.glb"), "--width", "8", "--height", "8"], capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "No camera in scene." in run.stderr
