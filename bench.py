@@ -214,7 +214,10 @@ def main():
     }
 
     if not args.no_frame:
-        out["frame"] = bench_frame(torch, dist, dev, rank, world, all_reduce)
+        try:
+            out["frame"] = bench_frame(torch, dist, dev, rank, world, all_reduce)
+        except Exception as e:  # noqa: BLE001  (the headline line above must still be printed)
+            out["frame"] = {"error": "%s: %s" % (type(e).__name__, e)}
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import oracle
