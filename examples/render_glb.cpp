@@ -3,10 +3,12 @@
 // rtgpu_gltf_load + rtgpu_scene_create, Renderer::render replaced by the adapter's GpuRenderer::render.
 //
 //   render_glb --scene scene.glb --width 500 --height 500 [--xstart .. --ystart .. --xend .. --yend ..]
-//              [--soupify] [--aageometry 4] [--aamaterial 4] [--seed 0] [--outputtype ppm|tile] [--output output]
+//              [--soupify] [--aageometry 4] [--aamaterial 4] [--seed 0] [--outputtype exr|png|ppm|tile] [--output output]
+//              [--exposure -2.5] [--gamma 2.2]
 //
-// Output: "tile" = the TILE exchange file of io/TileFile.cpp:8-27, "ppm" = the text PPM of io/PPMFile.cpp:4-24.
-// (exr / png output, photon mapping, tile merging and the preview window stay with the reference's executable.)
+// Output: "exr" (half floats, io/EXRWriter.cpp) and "png" (exposure + gamma, io/PNG.cpp) through the library's
+// writers, "tile" = the TILE exchange file of io/TileFile.cpp:8-27, "ppm" = the text PPM of io/PPMFile.cpp:4-24.
+// (Photon mapping, tile merging and the preview window stay with the reference's executable.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -50,14 +52,14 @@ void writePpm(const std::vector<float>& pixels, int width, int height, const std
 int main(int argc, char** argv)
 {
     std::map<std::string, std::string> opt = {{"scene", "scene.glb"}, {"width", "500"}, {"height", "500"}, {"xstart", "0"}, {"ystart", "0"},
-                                              {"outputtype", "tile"}, {"output", "output"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"}};
+                                              {"outputtype", "exr"}, {"output", "output"}, {"exposure", "-2.5"}, {"gamma", "2.2"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"}};
     bool soupify = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "unexpected argument %s\n", argv[i]); return -1; }
         a = a.substr(2);
         if (a == "soupify") { soupify = true; continue; }
-        if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output\n"); return 0; }
+        if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma\n"); return 0; }
         if (i + 1 >= argc) { std::fprintf(stderr, "option --%s needs a value\n", a.c_str()); return -1; }
         opt[a] = argv[++i];
     }
@@ -74,7 +76,7 @@ int main(int argc, char** argv)
     settings.seed = (uint32_t)std::strtoul(opt["seed"].c_str(), nullptr, 10);
     if (settings.geometryAAModifier <= 0 || settings.materialAAModifier <= 0) { std::fprintf(stderr, "Invalid AA settings!\n"); return -1; }
     const std::string type = opt["outputtype"];
-    if (type != "tile" && type != "ppm") { std::fprintf(stderr, "Unknown output type (this build writes tile and ppm).\n"); return -1; }
+    if (type != "exr" && type != "png" && type != "ppm" && type != "tile") { std::fprintf(stderr, "Invalid output type: %s\n", type.c_str()); return -1; }
 
     rtgpu_gltf* file = nullptr;
     try {
@@ -97,8 +99,11 @@ int main(int argc, char** argv)
         std::printf("Render done in %.3f milliseconds on the device.\n", stats.device_ms);
         std::printf("rays: primary %llu extension %llu shadow %llu\n", (unsigned long long)stats.primary_rays,
                     (unsigned long long)stats.extension_rays, (unsigned long long)stats.shadow_rays);
-        if (type == "tile") writeTile(pixels, width, height, tile, opt["output"] + ".tile");
-        else writePpm(pixels, width, height, opt["output"] + ".ppm");
+        const std::string outFile = opt["output"] + "." + type;   // outputfile.replace_extension(outputtype), exe/Raytracer.cpp:154
+        if (type == "exr") rtgpu::check(rtgpu_write_exr(outFile.c_str(), pixels.data(), width, height, 0));
+        else if (type == "png") rtgpu::check(rtgpu_write_png(outFile.c_str(), pixels.data(), width, height, std::atof(opt["exposure"].c_str()), std::atof(opt["gamma"].c_str())));
+        else if (type == "tile") writeTile(pixels, width, height, tile, outFile);
+        else writePpm(pixels, width, height, outFile);
     } catch (const std::exception& e) {
         if (file) rtgpu_gltf_free(file);
         std::fprintf(stderr, "%s\n", e.what());

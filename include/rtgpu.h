@@ -306,6 +306,16 @@ int rtgpu_gltf_camera(const rtgpu_gltf* g, rtgpu_camera* out);
 uint32_t rtgpu_gltf_camera_count(const rtgpu_gltf* g);
 void rtgpu_gltf_free(rtgpu_gltf* g);
 
+/* ---- frame-buffer output ---------------------------------------------------------------- */
+
+/* write_to_exr_file (io/EXRWriter.cpp:6-72): channels B, G, R as half floats (the executable's --outputtype exr,
+ * exe/Raytracer.cpp:347-350) or full floats; uncompressed scan lines.  rgb = width * height * 3 floats, the
+ * FrameBuffer layout. */
+int rtgpu_write_exr(const char* path, const float* rgb, int32_t width, int32_t height, int full_floats);
+/* write_to_png_file (io/PNG.cpp:7-28): pixel * 2^exposure, ^(1 / gamma), * 255 truncated and clamped to 255;
+ * 8-bit RGB.  The executable's defaults are exposure -2.5, gamma 2.2 (exe/Raytracer.cpp:69-70). */
+int rtgpu_write_png(const char* path, const float* rgb, int32_t width, int32_t height, double exposure, double gamma);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,7 @@ EXPORTS = [
     "rtgpu_generate_primary_device", "rtgpu_render", "rtgpu_render_device", "rtgpu_camera_from_transform",
     "rtgpu_scene_get_info", "rtgpu_trace_closest_count_device",
     "rtgpu_gltf_load", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
+    "rtgpu_write_exr", "rtgpu_write_png",
 ]
 
 _lib = None
@@ -72,6 +73,8 @@ def lib():
     L.rtgpu_camera_from_transform.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(abi.Camera)]
     L.rtgpu_scene_get_info.argtypes = [vp, C.POINTER(abi.SceneInfo)]
     L.rtgpu_trace_closest_count_device.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rtgpu_write_exr.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_int]
+    L.rtgpu_write_png.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_double, C.c_double]
     _lib = L
     return L
 
@@ -101,6 +104,18 @@ def camera_from_transform(fov_x_degrees: float, transform) -> abi.Camera:
     m = (C.c_double * 16)(*np.asarray(transform, dtype=np.float64).reshape(-1).tolist())
     _check(lib().rtgpu_camera_from_transform(float(fov_x_degrees), m, C.byref(cam)))
     return cam
+
+
+def write_exr(path, frame, full_floats=False):
+    """write_to_exr_file (io/EXRWriter.cpp:6-72); frame: (height, width, 3) float32."""
+    f = np.ascontiguousarray(frame, dtype=np.float32)
+    _check(lib().rtgpu_write_exr(str(path).encode(), f.ctypes.data_as(abi.c_float_p), f.shape[1], f.shape[0], 1 if full_floats else 0))
+
+
+def write_png(path, frame, exposure=-2.5, gamma=2.2):
+    """write_to_png_file (io/PNG.cpp:7-28) with the executable's default exposure and gamma."""
+    f = np.ascontiguousarray(frame, dtype=np.float32)
+    _check(lib().rtgpu_write_png(str(path).encode(), f.ctypes.data_as(abi.c_float_p), f.shape[1], f.shape[0], float(exposure), float(gamma)))
 
 
 def _f32(a, cols=3):
