@@ -24,6 +24,27 @@ def sha(a):
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 
+MATERIAL_SCENES = {
+    "coat": lambda: scenes.coat_scene(),
+    "glass": lambda: scenes.glass_scene(),
+    "glass_pane": lambda: scenes.glass_scene(view="pane"),
+    "textured": lambda: scenes.textured_scene(),
+    "bumps": lambda: scenes.textured_scene(normal_maps=True),
+    "lights_all": lambda: scenes.sun_scene("all"),
+}
+
+
+def material_images(render=None):
+    """name -> image; render(scene_data, camera, settings) defaults to the oracle on one thread."""
+    out = {}
+    for name, make in MATERIAL_SCENES.items():
+        sc, cam_m, yfov = make()
+        cam = oracle.camera_from_transform(scenes.x_fov_degrees(yfov, 40 / 30), cam_m)
+        st = abi.make_settings(40, 30, geometry_aa=2, material_aa=8, seed=11)
+        out[name] = render(sc, cam, st) if render else oracle.OracleScene(sc).render(cam, st, threads=1)[0]
+    return out
+
+
 def main():
     # G-1: config 1 (101 mesh instances + 16 analytic spheres), 640x480 pixel-centre primary rays and
     # the shadow ray from each hit towards the point light
@@ -60,6 +81,8 @@ def main():
     img, stats = BS.render(bcam, bst, threads=1)
     np.savez_compressed(os.path.join(HERE, "box_render_48x36_g4_m4_seed11.npz"), image=img,
                         rays=np.array([stats.primary_rays, stats.extension_rays, stats.shadow_rays], dtype=np.uint64))
+    # G-5: the closures beyond diffuse / glossy, one small image per scene
+    np.savez_compressed(os.path.join(HERE, "materials_render_40x30_g2_m8_seed11.npz"), **material_images())
     print("fixtures written to", HERE)
 
 

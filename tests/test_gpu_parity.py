@@ -295,6 +295,22 @@ def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
         assert rel_rmse(img, gold["image"]) <= 1e-4
 
 
+def test_material_renders_match_the_committed_images():
+    """The GPU integrator against tests/golden/materials_render_40x30_g2_m8_seed11.npz (images the oracle
+    rendered when the closures were written): relative RMSE <= 1e-4 per scene."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(GOLDEN, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLDEN, "materials_render_40x30_g2_m8_seed11.npz"))
+
+    def gpu(sc, cam, st):
+        with api.Scene(sc) as scene:
+            return api.Renderer().render(scene, cam, st)[0]
+    for name, img in mg.material_images(gpu).items():
+        assert rel_rmse(img, g[name]) <= 1e-4, name
+
+
 def test_render_interior_glossy_floor_matches_oracle():
     """Larger diffuse + glossy interior (area + point light): finite everywhere and equal to the oracle at
     matched streams; rays with a NaN direction (a reflection off a degenerate normal) find nothing on

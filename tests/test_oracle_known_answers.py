@@ -157,6 +157,21 @@ def test_golden_box_render():
     assert img.min() >= 0 and np.isfinite(img).all() and img.mean() > 0.05
 
 
+def test_golden_material_renders():
+    """Glass, add, mix, textured, normal-mapped and multi-light scenes against the committed images
+    (tests/golden/make_golden.py): guards the oracle's closures against silent changes."""
+    sys_path_golden = os.path.join(GOLDEN)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(sys_path_golden, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = np.load(os.path.join(GOLDEN, "materials_render_40x30_g2_m8_seed11.npz"))
+    got = mg.material_images(lambda sc, cam, st: oracle.OracleScene(sc).render(cam, st)[0])
+    assert sorted(got) == sorted(g.files)
+    for name, img in got.items():
+        assert np.array_equal(img, g[name]), name
+
+
 def test_render_tile_equals_crop_of_full_frame():
     """Renderer::render only writes inside the tile and a pixel's value does not depend on the tile."""
     sc, cam_m, yfov = scenes.box_scene()
