@@ -287,6 +287,50 @@ int rtgpu_scene_get_info(const rtgpu_scene* scene, rtgpu_scene_info* out);
 int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_origins, const float* d_dirs,
                                      uint64_t n, uint32_t* d_counts, void* hip_stream);
 
+/* ---- photon map ---------------------------------------------------------------------------- */
+
+/* PhotonMapMode (scene/renderable/Scene.h) as the executable's --pmmode sets it.  "full": a diffuse vertex reads
+ * the map instead of sampling once `depth` earlier vertices of its path were diffuse (specularity < 0.8),
+ * material/DiffuseMaterial.cpp:39-80.  "caustics" (DiffuseMaterial.cpp:104-135, GlassMaterial.cpp:31-38) is
+ * accepted by the photon tracer only (it selects which photons are stored); rendering with it is not built. */
+typedef enum rtgpu_photon_map_mode {
+    RTGPU_PM_NONE = 0,
+    RTGPU_PM_CAUSTICS = 1,
+    RTGPU_PM_FULL = 2
+} rtgpu_photon_map_mode;
+
+typedef struct rtgpu_photon { /* photonmapping/Photon.h:7-24 */
+    float pos[3];
+    float normal[3];  /* surfaceNormal: the hit's shading normal */
+    float energy[3];  /* the photon's energy when it arrived */
+    uint32_t is_caustic;
+} rtgpu_photon;
+
+/* PhotonMapBuilder::buildPhotonMap (photonmapping/PhotonMapBuilder.cpp:15-41): traces photons from every point
+ * and area light (PhotonTracer::tracePhotons, photonmapping/PhotonTracer.cpp:8-172, at most 12 vertices each),
+ * builds the search tree over them on the GPU's host and keeps both with the scene; later renders of the scene
+ * use the map (Scene::getPhotonMap).  rays_per_*: the executable's --pmrayspointlamp / --pmraysarealamp.
+ * Photons are kept in emission order (light, ray, vertex), so the map depends only on the arguments. */
+int rtgpu_scene_build_photon_map(rtgpu_scene* scene, int32_t mode, int32_t depth, uint64_t rays_per_point_light,
+                                 uint64_t rays_per_area_light, uint32_t seed, uint64_t* n_photons);
+/* The executable's --savepm / --loadpm as memory transfers: copy the photons out (at most `capacity`; *n receives
+ * the number the map holds) or install a photon list (mode NONE removes the map). */
+int rtgpu_scene_get_photons(const rtgpu_scene* scene, rtgpu_photon* out, uint64_t capacity, uint64_t* n);
+int rtgpu_scene_set_photons(rtgpu_scene* scene, const rtgpu_photon* photons, uint64_t n, int32_t mode, int32_t depth);
+
+/* The radiance estimate's gather, KDTree::getElementsNearestTo as DiffuseMaterial calls it
+ * (material/DiffuseMaterial.cpp:62-75): the 20 nearest photons whose surfaceNormal has a non-negative dot product
+ * with `direction`.  count = photons found, max_dist = the search radius the reference ends with (distance of the
+ * 20th photon; FLT_MAX when fewer than 20 but at least one were found; 1e9 when none), energy = their energies
+ * summed nearest first.  Host arrays: points / directions n * 3 floats. */
+typedef struct rtgpu_photon_gather {
+    uint32_t count;
+    float max_dist;
+    float energy[3];
+} rtgpu_photon_gather;
+int rtgpu_scene_gather_photons(const rtgpu_scene* scene, const float* points, const float* directions, uint64_t n,
+                               rtgpu_photon_gather* out);
+
 /* ---- scene ingestion ------------------------------------------------------------------- */
 
 /* A binary glTF file flattened into a scene description in host memory: loadGLTFScene (io/GLTF.cpp:682-705:

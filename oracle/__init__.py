@@ -36,6 +36,14 @@ def lib():
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_create.argtypes = [C.POINTER(abi.SceneDesc), C.c_int]
         L.orc_scene_destroy.argtypes = [C.c_void_p]
+        L.orc_build_photon_map.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int]
+        L.orc_build_photon_map.restype = C.c_uint64
+        L.orc_get_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64]
+        L.orc_get_photons.restype = C.c_uint64
+        L.orc_set_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_int32, C.c_int32]
+        L.orc_set_photons.restype = None
+        L.orc_gather_photons.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_int]
+        L.orc_gather_photons.restype = None
         L.orc_trace_closest.argtypes = [C.c_void_p, fp, fp, C.c_uint64, C.c_void_p, u32p, C.c_int]
         L.orc_trace_any.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, u8p, C.c_int]
         L.orc_brute_closest.argtypes = [C.c_void_p, fp, fp, C.c_uint64, C.c_void_p, u32p, C.c_int]
@@ -129,6 +137,29 @@ class OracleScene:
         o, d = _f32(o).reshape(-1, 3), _f32(d).reshape(-1, 3)
         out = np.empty(o.shape[0], dtype=np.uint8)
         lib().orc_ray_hits_instance_box(self._h, _fp(o), _fp(d), o.shape[0], int(inst), out.ctypes.data_as(abi.c_u8_p))
+        return out
+
+    # ---- photon map (photonmapping/PhotonMapBuilder.cpp:15-41) ----
+    def build_photon_map(self, mode, depth, rays_per_point_light, rays_per_area_light, seed=0, threads=None):
+        return int(lib().orc_build_photon_map(self._h, int(mode), int(depth), int(rays_per_point_light), int(rays_per_area_light),
+                                              int(seed), threads or self.threads))
+
+    def photons(self):
+        n = int(lib().orc_get_photons(self._h, None, 0))
+        out = np.empty(n, dtype=abi.PHOTON_DTYPE)
+        if n:
+            lib().orc_get_photons(self._h, out.ctypes.data_as(C.c_void_p), n)
+        return out
+
+    def set_photons(self, photons, mode, depth):
+        ph = np.ascontiguousarray(photons, dtype=abi.PHOTON_DTYPE)
+        lib().orc_set_photons(self._h, ph.ctypes.data_as(C.c_void_p), len(ph), int(mode), int(depth))
+
+    def gather_photons(self, points, dirs, threads=None):
+        p, d = _f32(points).reshape(-1, 3), _f32(dirs).reshape(-1, 3)
+        out = np.empty(len(p), dtype=abi.GATHER_DTYPE)
+        lib().orc_gather_photons(self._h, p.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), len(p),
+                                 out.ctypes.data_as(C.c_void_p), threads or self.threads)
         return out
 
     def render(self, cam: abi.Camera, st: abi.RenderSettings, threads=None):

@@ -618,6 +618,12 @@ struct orc_scene {
     std::vector<Tex> textures;
     bool hasEnv = false;
     RGBf envRadiance; // color * intensity, ColorEnvironment.cpp:6-9
+    // Scene::photonMap / photonMapMode / photonMapDepth: photons + the tree of photonmapping/KDTreeBuilder.h
+    std::vector<rtgpu_photon> photons;
+    struct KdNode { int32_t child[2]; uint32_t photon; int32_t axis; };
+    std::vector<KdNode> kd;
+    int32_t kdRoot = -1;
+    int pmMode = RTGPU_PM_NONE, pmDepth = 0;
 };
 
 namespace {
@@ -913,6 +919,8 @@ struct RenderCtx {
     const orc_scene& S;
     rtgpu_render_stats* stats;
     uint64_t primary = 0, extension = 0, shadow = 0;
+    const std::vector<struct TransportNode>* path = nullptr;   // TransportContext::path / curI of the vertex being sampled
+    int curI = 0;
 };
 
 // neePointLight, material/NextEventEstimation.cpp:8-26
@@ -1021,6 +1029,135 @@ RGBf nee_sample(RenderCtx& R, V3 hitpoint, int sampleI, int sampleCount, const R
     return RGBf{};
 }
 
+// ---- photon map: tree and gather -----------------------------------------------------------
+// KDTreeBuilder::buildNode / buildTree, photonmapping/KDTreeBuilder.h:178-231: the slice arrives sorted along
+// `presorted`; three or more photons are sorted along the next axis and split at count / 2, two photons make a
+// node from the first with the second as its right child, one photon is a leaf
+int32_t kd_build(orc_scene& S, uint32_t* idx, size_t count, int presorted)
+{
+    if (count == 0) return -1;
+    const int32_t me = (int32_t)S.kd.size();
+    S.kd.push_back(orc_scene::KdNode{{-1, -1}, 0, 0});
+    if (count == 1) {
+        S.kd[me].photon = idx[0];
+        return me;
+    }
+    if (count == 2) {
+        S.kd[me].photon = idx[0];
+        S.kd[me].axis = presorted;
+        const int32_t right = kd_build(S, idx + 1, 1, presorted);
+        S.kd[me].child[1] = right;
+        return me;
+    }
+    const int cur = (presorted + 1) % 3;
+    std::sort(idx, idx + count, [&](uint32_t a, uint32_t b) { return S.photons[a].pos[cur] < S.photons[b].pos[cur]; });
+    const size_t mid = count / 2;
+    S.kd[me].photon = idx[mid];
+    S.kd[me].axis = cur;
+    const int32_t left = kd_build(S, idx, mid, cur);
+    const int32_t right = kd_build(S, idx + mid + 1, count - mid - 1, cur);
+    S.kd[me].child[0] = left;
+    S.kd[me].child[1] = right;
+    return me;
+}
+// KDTreeBuilder::build, photonmapping/KDTreeBuilder.h:258-276
+void kd_build_all(orc_scene& S)
+{
+    S.kd.clear();
+    S.kdRoot = -1;
+    if (S.photons.empty()) return;
+    std::vector<uint32_t> idx(S.photons.size());
+    for (size_t i = 0; i < idx.size(); ++i) idx[i] = (uint32_t)i;
+    std::sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return S.photons[a].pos[0] < S.photons[b].pos[0]; });
+    S.kd.reserve(idx.size());
+    S.kdRoot = kd_build(S, idx.data(), idx.size(), 0);
+}
+
+struct Gather { // the state of one KDTree::getElementsNearestTo call
+    const orc_scene& S;
+    V3 target, dir;
+    unsigned count;
+    std::vector<int64_t> results; // photon indices, nearest first; -1 = empty (nullptr in the reference)
+    V3 pos(uint32_t ph) const { return mk(S.photons[ph].pos); }
+    bool filter(uint32_t ph) const { return dot(dir, mk(S.photons[ph].normal)) >= 0; } // DiffuseMaterial.cpp:66-68
+    // KDTreeNode::insert, photonmapping/KDTree.h:225-245
+    float insert(uint32_t ph)
+    {
+        auto key = [&](int64_t r) { return r < 0 ? 1E99 : (double)dot(pos((uint32_t)r) - target, pos((uint32_t)r) - target); };
+        auto it = std::lower_bound(results.begin(), results.end(), (int64_t)ph, [&](int64_t a, int64_t b) { return key(a) < key(b); });
+        if (it != results.end() && *it != (int64_t)ph) {
+            results.insert(it, (int64_t)ph);
+            results.pop_back();
+        }
+        const int64_t last = results.back();
+        if (last < 0) return std::numeric_limits<float>::max();
+        return norm(pos((uint32_t)last) - target);
+    }
+    // KDTreeNode::getElementsNearestTo, photonmapping/KDTree.h:90-164
+    void visit(int32_t ni, bool targetInside, float& searchRadius, unsigned& found, V3 lo, V3 hi)
+    {
+        const orc_scene::KdNode& n = S.kd[ni];
+        const V3 position = pos(n.photon);
+        if (n.child[0] < 0 && n.child[1] < 0) {
+            if (norm(position - target) < searchRadius && filter(n.photon)) {
+                searchRadius = insert(n.photon);
+                found = std::min(found + 1, count);
+            }
+            return;
+        }
+        const int axis = n.axis;
+        auto comp = [&](V3 v) { return axis == 0 ? v.x : (axis == 1 ? v.y : v.z); };
+        const int inChild = comp(position) < comp(target) ? 1 : 0;
+        // AABB::split at the node's plane: child 0 keeps the low side
+        V3 lo0 = lo, hi0 = hi, lo1 = lo, hi1 = hi;
+        if (axis == 0) { hi0.x = position.x; lo1.x = position.x; }
+        else if (axis == 1) { hi0.y = position.y; lo1.y = position.y; }
+        else { hi0.z = position.z; lo1.z = position.z; }
+        if (n.child[inChild] >= 0) visit(n.child[inChild], targetInside, searchRadius, found, inChild ? lo1 : lo0, inChild ? hi1 : hi0);
+        if (norm(position - target) < searchRadius && filter(n.photon)) {
+            searchRadius = insert(n.photon);
+            found = std::min(found + 1, count);
+        }
+        const int other = (inChild + 1) % 2;
+        if (n.child[other] >= 0) {
+            float distanceToSplitPlane;
+            if (targetInside) distanceToSplitPlane = std::abs(comp(position) - comp(target));
+            else {
+                V3 projection{std::min(std::max(target.x, lo.x), hi.x), std::min(std::max(target.y, lo.y), hi.y), std::min(std::max(target.z, lo.z), hi.z)};
+                distanceToSplitPlane = norm(projection - target);
+            }
+            if (distanceToSplitPlane <= searchRadius) visit(n.child[other], false, searchRadius, found, other ? lo1 : lo0, other ? hi1 : hi0);
+        }
+    }
+};
+
+// photonMap->getElementsNearestTo(hitpoint, 20, 1E9, filter, photons) and the energy sum of DiffuseMaterial.cpp:62-75
+rtgpu_photon_gather gather_photons(const orc_scene& S, V3 target, V3 dir, unsigned k = 20)
+{
+    rtgpu_photon_gather out{};
+    float searchRadius = 1E9;
+    unsigned found = 0;
+    Gather g{S, target, dir, k, std::vector<int64_t>(k, -1)};
+    if (S.kdRoot >= 0) {
+        const float big = std::numeric_limits<float>::max();
+        g.visit(S.kdRoot, true, searchRadius, found, V3{-big, -big, -big}, V3{big, big, big});
+    }
+    out.count = found;
+    out.max_dist = searchRadius;
+    RGBf value;
+    for (unsigned i = 0; i < found; ++i) {
+        const rtgpu_photon& ph = S.photons[(size_t)g.results[i]];
+        value = rgb_add(value, RGBf{ph.energy[0], ph.energy[1], ph.energy[2]});
+    }
+    out.energy[0] = value.r; out.energy[1] = value.g; out.energy[2] = value.b;
+    return out;
+}
+
+// DiffuseMaterial's test in PhotonMapMode::full (material/DiffuseMaterial.cpp:40-54, 230-244): has the path passed
+// `photonMapDepth` vertices with specularity < 0.8 before vertex curI?
+struct TransportNode;
+bool diffuse_reads_map(const orc_scene& S, const std::vector<TransportNode>& path, int curI);
+
 // ---- transport ---------------------------------------------------------------------------
 struct TransportNode { // material/IMaterial.h:17-30 + the per-material TransportMetaData
     SceneHit hit;
@@ -1033,6 +1170,9 @@ struct TransportNode { // material/IMaterial.h:17-30 + the per-material Transpor
     RGBf directLighting;       // DiffuseMaterial
     RGBf neeRadiance;          // GlossyMaterial
     int lightHit = -1;         // GlossyMaterial, index into areaLights
+    float specularity = 0;     // TransportNode::specularity (IMaterial.h:23): what DiffuseMaterial counts in photon-map mode
+    bool isPhotonMapRay = false; // DiffuseMaterial: the vertex reads the photon map
+    RGBf photonLighting;
     // GlassMaterial's TransportMetaData (material/GlassMaterial.cpp:11-18).  The reference keeps metadata in
     // a tree with one slot per MixMaterial branch (utility/DynAllocTree.h:118-131: depth 3, two children),
     // and a slot survives every re-sampling pass of the node (renderer/Renderer.cpp:246 keeps the node).
@@ -1048,6 +1188,15 @@ struct TransportNode { // material/IMaterial.h:17-30 + the per-material Transpor
     uint32_t addFirst[4] = {0, 0, 0, 0};
     int nAdd = 0;
 };
+
+bool diffuse_reads_map(const orc_scene& S, const std::vector<TransportNode>& path, int curI)
+{
+    if (S.pmMode != RTGPU_PM_FULL) return false;
+    int curDiffuseI = 0;
+    for (int i = 0; i < curI; ++i)
+        if (path[i].specularity < 0.8) curDiffuseI++;
+    return curDiffuseI >= S.pmDepth;
+}
 
 uint32_t hit_material(const orc_scene& S, const SceneHit& h) // Model material / CompositeMaterial::findMaterial
 {
@@ -1091,20 +1240,20 @@ float mat_mix_factor(const rtgpu_material& m, const SceneHit& h)
 // IMaterial::hasVariance: Diffuse (DiffuseMaterial.cpp:228-247, no photon map) true; Glossy
 // (GlossyMaterial.cpp:226-229) roughness > 0; Emissive false; Transparent
 // (TransparentMaterial.cpp:23-26) false; Mix (MixMaterial.cpp:59-65)
-bool mat_has_variance(const orc_scene& S, uint32_t mi, const SceneHit& h)
+bool mat_has_variance(const orc_scene& S, uint32_t mi, const SceneHit& h, bool diffuseReadsMap = false)
 {
     const rtgpu_material& m = S.materials[mi];
     switch (m.type) {
-    case RTGPU_MAT_DIFFUSE: return true;
+    case RTGPU_MAT_DIFFUSE: return !diffuseReadsMap;   // DiffuseMaterial.cpp:228-247
     case RTGPU_MAT_GLOSSY: return m.roughness > 0.0f;
     case RTGPU_MAT_EMISSIVE: return false;
     case RTGPU_MAT_TRANSPARENT: return false;
     case RTGPU_MAT_GLASS: return true;  // GlassMaterial.cpp:254-257
-    case RTGPU_MAT_ADD: return mat_has_variance(S, m.first, h) || mat_has_variance(S, m.second, h); // AddMaterial.cpp:25-28
+    case RTGPU_MAT_ADD: return mat_has_variance(S, m.first, h, diffuseReadsMap) || mat_has_variance(S, m.second, h, diffuseReadsMap); // AddMaterial.cpp:25-28
     case RTGPU_MAT_CONSTMIX:
     case RTGPU_MAT_FRESNELMIX: {
         float mf = mat_mix_factor(m, h);
-        bool noVar = (mf == 0.0f && !mat_has_variance(S, m.first, h)) || (mf == 1.0f && !mat_has_variance(S, m.second, h));
+        bool noVar = (mf == 0.0f && !mat_has_variance(S, m.first, h, diffuseReadsMap)) || (mf == 1.0f && !mat_has_variance(S, m.second, h, diffuseReadsMap));
         return !noVar;
     }
     }
@@ -1183,6 +1332,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         tn.leafMat = mi;
         tn.leafSlot = metaIndex;
         tn.isNEERay = false;
+        tn.specularity = 1.0f;
         TransportNode::GlassMeta& meta = tn.glass[metaIndex];
         if (!meta.used) {
             meta = TransportNode::GlassMeta{};
@@ -1246,6 +1396,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     }
     case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::sampleTransport, material/TransparentMaterial.cpp:3-11
         tn.leafMat = mi;
+        tn.specularity = 1.0f;
         tn.isEmissive = false;
         tn.pathTerminationChance = 0.01;
         tn.transportDirection = tn.hit.rd;
@@ -1258,6 +1409,18 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::sampleTransport, material/DiffuseMaterial.cpp:24-138 (no photon map)
         tn.leafMat = mi;
         V3 normal = shading_normal(S, m, tn.hit);
+        tn.specularity = 0.0f;
+        tn.isPhotonMapRay = false;
+        if (diffuse_reads_map(S, *R.path, R.curI)) { // material/DiffuseMaterial.cpp:56-80
+            tn.pathTerminationChance = 1.0f;
+            tn.isEmissive = true;
+            tn.isPhotonMapRay = true;
+            tn.isNEERay = false;
+            rtgpu_photon_gather g = gather_photons(S, tn.hit.hitpoint(), -tn.hit.rd);
+            RGBf value{g.energy[0], g.energy[1], g.energy[2]};
+            tn.photonLighting = rgb_div_d(rgb_div_d(rgb_scale_d(value, m.intensity), PI * g.max_dist * g.max_dist), PI);
+            return;
+        }
         tn.pathTerminationChance = 0.1f;
         tn.isEmissive = false;
         bool useNEE = rc.unit(DIM_NEE_CHOICE) > 0.5f;
@@ -1281,6 +1444,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         V3 hitpoint = tn.hit.hitpoint();
         V3 normal = shading_normal(S, m, tn.hit);   // meta->normal
         const float roughness = m.roughness;
+        tn.specularity = 1.0f - roughness;
         bool neeEnabled = roughness > 0;
         bool useNEE = neeEnabled && rc.unit(DIM_NEE_CHOICE) > 0.5;
         tn.isNEERay = useNEE;
@@ -1364,6 +1528,7 @@ RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf in
     }
     switch (m.type) {
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::bsdf, material/DiffuseMaterial.cpp:140-197
+        if (tn.isPhotonMapRay) return rgb_mul(color, tn.photonLighting);   // :154-166 (mode full)
         double angle = std::max(0.0f, dot(shading_normal(S, m, tn.hit), tn.transportDirection));
         RGBf value;
         if (tn.isNEERay) {
@@ -1448,7 +1613,9 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
     do {
         TransportNode& cur = path[curI];
         uint32_t mi = hit_material(S, cur.hit);
-        bool curVar = mat_has_variance(S, mi, cur.hit);
+        R.path = &path;
+        R.curI = curI;
+        bool curVar = mat_has_variance(S, mi, cur.hit, diffuse_reads_map(S, path, curI));
         bool isFirstVar = curVar && !hasPassedVariance;
         int sampleCount = isFirstVar ? materialAA : 1;
         int sampleI = isFirstVar ? sampleJ : 0;
@@ -1594,7 +1761,7 @@ RGBf render_pixel(RenderCtx& R, const rtgpu_camera& cam, const rtgpu_render_sett
         bool terminated = sample_path(R, path, 0, st.max_path_length, M, 0, key);
         int firstVar = 0;
         for (; firstVar < (int)path.size(); ++firstVar)
-            if (mat_has_variance(S, hit_material(S, path[firstVar].hit), path[firstVar].hit)) break;
+            if (mat_has_variance(S, hit_material(S, path[firstVar].hit), path[firstVar].hit, diffuse_reads_map(S, path, firstVar))) break;
         RGBf matSample;
         if (!terminated) matSample = path_energy(S, path);
         if (firstVar < (int)path.size()) {
@@ -1628,6 +1795,155 @@ void parallel_for(uint64_t n, int n_threads, const F& f)
             }
         });
     for (auto& t : th) t.join();
+}
+
+// ---- photon tracing --------------------------------------------------------------------------
+// Random numbers of a photon: rand_unit(seed, kPhotonPixel | light, ray, vertex, dim); vertex kVertexEmit for the
+// emission, the bounce number afterwards.
+constexpr uint32_t kPhotonPixel = 0x40000000u;
+constexpr uint32_t kVertexEmit = 254;
+
+// Rand::sampleStdNormalDist (math/FastRandom.h) stand-in: Box-Muller on two uniform draws
+inline float std_normal(float u1, float u2) { return (float)(std::sqrt(-2.0 * std::log(1.0 - (double)u1)) * std::cos(2.0 * PI * (double)u2)); }
+
+// IMaterial::interactPhoton of the closures: direction, energy, diffuseness
+void interact_photon(const orc_scene& S, const SceneHit& hit, uint32_t mi, RGBf incoming, const RandCtx& rc, int level, V3& dir, RGBf& energy, float& diffuseness)
+{
+    const rtgpu_material& m = S.materials[mi];
+    switch (m.type) {
+    case RTGPU_MAT_CONSTMIX:
+    case RTGPU_MAT_FRESNELMIX: // MixMaterial::interactPhoton, material/MixMaterial.cpp:47-57
+        interact_photon(S, hit, rc.unit(DIM_MIX0 + level) > mat_mix_factor(m, hit) ? m.first : m.second, incoming, rc, level + 1, dir, energy, diffuseness);
+        return;
+    case RTGPU_MAT_ADD: // AddMaterial::interactPhoton, material/AddMaterial.cpp:19-23: the first child
+        interact_photon(S, hit, m.first, incoming, rc, level + 1, dir, energy, diffuseness);
+        return;
+    case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::interactPhoton, material/DiffuseMaterial.cpp:206-226
+        RGBf color{m.color[0], m.color[1], m.color[2]};
+        if (m.texture != 0) color = texture_get(S.textures[m.texture - 1], std::abs(std::fmod(hit.u, 1.0f)), std::abs(std::fmod(hit.v, 1.0f)));
+        Basis basis = basis_from(shading_normal(S, m, hit));
+        V3 l = cosine_hemisphere(rc.unit(DIM_SQUARE_X), rc.unit(DIM_SQUARE_Y));
+        dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
+        energy = rgb_mul(color, incoming);
+        diffuseness = 1.0f;
+        return;
+    }
+    case RTGPU_MAT_GLOSSY: { // GlossyMaterial::interactPhoton, material/GlossyMaterial.cpp:209-224
+        V3 micro = normalized(vndf_sample(shading_normal(S, m, hit), -hit.rd, m.roughness, rc.unit(DIM_SQUARE_X), rc.unit(DIM_SQUARE_Y)));
+        dir = hit.rd + ((float)(2.0 * dot(micro, -hit.rd)) * micro);
+        energy = incoming;
+        diffuseness = m.roughness;
+        return;
+    }
+    case RTGPU_MAT_GLASS: { // GlassMaterial::interactPhoton + samplePhotonDirection, material/GlassMaterial.cpp:180-252
+        V3 normal = hit.normal;
+        bool attenuate = dot(normal, hit.rd) < 0;
+        V3 incomingDir = hit.rd, objToIncoming = -incomingDir;
+        V3 reflectedRayDir = (-objToIncoming) + ((float)(2.0 * dot(normal, objToIncoming)) * normal);
+        double nDotWo = dot(normal, objToIncoming);
+        double incomingAngle = nDotWo;
+        bool isInternalRay = nDotWo < 0;
+        double curRelIor = m.intensity / 1.0;
+        if (isInternalRay) curRelIor = 1.0 / curRelIor;
+        double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+        if (cosTransmissionSqr < 0) {
+            dir = reflectedRayDir;
+        } else {
+            if (isInternalRay) { nDotWo = -nDotWo; incomingAngle = -incomingAngle; normal = -normal; }
+            double cosRefractAngle = std::sqrt(cosTransmissionSqr);
+            V3 transmittedRayDir = (incomingDir / (float)curRelIor) - ((float)(cosRefractAngle - (incomingAngle / curRelIor)) * normal);
+            double rs = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+            double rp = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+            double kr = ((rs * rs) + (rp * rp)) / 2.0;
+            double reflectionWeight = kr / (kr + (1.0 - kr));
+            dir = (double)rc.unit(DIM_GLASS) < reflectionWeight ? reflectedRayDir : transmittedRayDir;
+        }
+        energy = incoming;
+        if (attenuate) {
+            double power = m.roughness * hit.t;
+            energy = rgb_mul(incoming, RGBf{(float)std::pow(m.color[0], power), (float)std::pow(m.color[1], power), (float)std::pow(m.color[2], power)});
+        }
+        diffuseness = 0.0f;
+        return;
+    }
+    case RTGPU_MAT_TRANSPARENT: // TransparentMaterial.cpp:18-21
+        dir = hit.rd; energy = incoming; diffuseness = 0.0f;
+        return;
+    default: // EmissiveMaterial.cpp:24-27
+        dir = -hit.rd; energy = RGBf{}; diffuseness = 0.0f;
+        return;
+    }
+}
+
+// PhotonDriver::trace, photonmapping/PhotonTracer.cpp:12-58
+void trace_photon(const orc_scene& S, V3 o, V3 d, RGBf photonEnergy, int mode, uint32_t seed, uint32_t pixel, uint32_t ray, std::vector<rtgpu_photon>& acc)
+{
+    bool hasPassedSpecular = false;
+    for (int i = 0; i < 12; ++i) {
+        SceneHit hit = scene_trace(S, o, d);
+        if (!hit.ok) break;
+        V3 hitpoint = hit.hitpoint();
+        RandCtx rc{seed, pixel, ray, (uint32_t)i};
+        V3 newDir;
+        RGBf newEnergy;
+        float diffuseness;
+        interact_photon(S, hit, hit_material(S, hit), photonEnergy, rc, 0, newDir, newEnergy, diffuseness);
+        newDir = normalized(newDir);
+        bool isDiffuseTransport = diffuseness >= 0.2;
+        bool isCaustic = isDiffuseTransport && hasPassedSpecular;
+        if ((mode == RTGPU_PM_CAUSTICS && isCaustic) || (mode == RTGPU_PM_FULL && isDiffuseTransport)) {
+            rtgpu_photon ph{{hitpoint.x, hitpoint.y, hitpoint.z}, {hit.normal.x, hit.normal.y, hit.normal.z}, {photonEnergy.r, photonEnergy.g, photonEnergy.b}, isCaustic ? 1u : 0u};
+            acc.push_back(ph);
+        }
+        hasPassedSpecular = hasPassedSpecular || !isDiffuseTransport;
+        o = hitpoint + (newDir * 0.00005f);
+        d = newDir;
+        photonEnergy = newEnergy;
+    }
+}
+
+// The rays PhotonTracer::tracePhotons emits (photonmapping/PhotonTracer.cpp:139-172) in task order: for each light the
+// batches of createBatches (utility/Batcher.h: 10 000 rays each; a last partial batch is issued twice) -- counted
+// over photonsPerPointLight for both kinds of light, as the reference does.
+struct PhotonBatch { uint32_t light; bool area; uint64_t start, end, firstRay; };
+std::vector<PhotonBatch> photon_batches(const orc_scene& S, uint64_t perPoint)
+{
+    std::vector<PhotonBatch> out;
+    const uint64_t batchSize = 10000;
+    auto add = [&](uint32_t light, bool area) {
+        uint64_t ray = 0;
+        for (uint64_t i = 0; i < perPoint; i += batchSize) { uint64_t e = std::min(i + batchSize, perPoint); out.push_back({light, area, i, e, ray}); ray += e - i; }
+        uint64_t rem = perPoint % batchSize;
+        if (rem > 0) out.push_back({light, area, perPoint - rem, perPoint, ray});
+    };
+    for (uint32_t l = 0; l < S.pointLights.size(); ++l) add(l, false);
+    for (uint32_t l = 0; l < S.areaLights.size(); ++l) add(l, true);
+    return out;
+}
+
+void emit_and_trace(const orc_scene& S, const PhotonBatch& b, uint64_t k, int mode, uint64_t perPoint, uint64_t perArea, uint32_t seed, std::vector<rtgpu_photon>& acc)
+{
+    const uint32_t ray = (uint32_t)(b.firstRay + k);
+    if (!b.area) { // PointLightPhotonTracingTask::execute, :84-96
+        const rtgpu_point_light& L = S.pointLights[b.light];
+        const uint32_t pixel = kPhotonPixel | b.light;
+        RandCtx rc{seed, pixel, ray, kVertexEmit};
+        RGBf energyPerPhoton = rgb_scale_d(RGBf{L.color[0], L.color[1], L.color[2]}, L.intensity / (double)perPoint);
+        float x = std_normal(rc.unit(0), rc.unit(1)), y = std_normal(rc.unit(2), rc.unit(3)), z = std_normal(rc.unit(4), rc.unit(5));
+        float len = std::sqrt(x * x + y * y + z * z);   // sampleUniformSphere(1.0), math/Sampler.h:42-49
+        trace_photon(S, mk(L.pos), V3{1.0f * x / len, 1.0f * y / len, 1.0f * z / len}, energyPerPhoton, mode, seed, pixel, ray, acc);
+    } else { // AreaLightPhotonTracingTask::execute, :121-137
+        const rtgpu_area_light& L = S.areaLights[b.light];
+        const uint32_t pixel = kPhotonPixel | (uint32_t)(S.pointLights.size() + b.light);
+        RandCtx rc{seed, pixel, ray, kVertexEmit};
+        RGBf energyPerPhoton = rgb_div_f(light_energy(L.color, L.intensity), (float)perArea);
+        V3 a = mk(L.a), bb = mk(L.b), c = mk(L.c);
+        Basis basis = basis_from(cross(bb - a, c - a));
+        V3 photonPos = area_light_point(L, (int)(b.end - b.start), (int)k, rc.unit(DIM_AREA_U), rc.unit(DIM_AREA_V));
+        V3 l = cosine_hemisphere(rc.unit(DIM_SQUARE_X), rc.unit(DIM_SQUARE_Y));
+        V3 dir = normalized(((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z));
+        trace_photon(S, photonPos + (dir * 0.0001f), dir, energyPerPhoton, mode, seed, pixel, ray, acc);
+    }
 }
 
 } // namespace
@@ -1814,6 +2130,46 @@ void orc_render(const orc_scene* s, const rtgpu_camera* cam, const rtgpu_render_
         stats->primary_rays = primary; stats->extension_rays = extension; stats->shadow_rays = shadow;
         stats->device_ms = 0;
     }
+}
+
+
+// PhotonMapBuilder::buildPhotonMap, photonmapping/PhotonMapBuilder.cpp:15-41.  Photons are kept in emission order.
+uint64_t orc_build_photon_map(orc_scene* s, int32_t mode, int32_t depth, uint64_t rays_per_point_light, uint64_t rays_per_area_light, uint32_t seed, int n_threads)
+{
+    s->photons.clear();
+    s->pmMode = mode;
+    s->pmDepth = depth;
+    if (mode != RTGPU_PM_NONE) {
+        std::vector<PhotonBatch> batches = photon_batches(*s, rays_per_point_light);
+        std::vector<std::vector<rtgpu_photon>> parts(batches.size());
+        parallel_for(batches.size(), n_threads, [&](uint64_t b0, uint64_t b1) {
+            for (uint64_t b = b0; b < b1; ++b)
+                for (uint64_t k = 0; k < batches[b].end - batches[b].start; ++k)
+                    emit_and_trace(*s, batches[b], k, mode, rays_per_point_light, rays_per_area_light, seed, parts[b]);
+        });
+        for (auto& p : parts) s->photons.insert(s->photons.end(), p.begin(), p.end());
+    }
+    kd_build_all(*s);
+    return s->photons.size();
+}
+uint64_t orc_get_photons(const orc_scene* s, rtgpu_photon* out, uint64_t capacity)
+{
+    const uint64_t n = std::min<uint64_t>(capacity, s->photons.size());
+    if (out && n) std::memcpy(out, s->photons.data(), n * sizeof(rtgpu_photon));
+    return s->photons.size();
+}
+void orc_set_photons(orc_scene* s, const rtgpu_photon* photons, uint64_t n, int32_t mode, int32_t depth)
+{
+    s->photons.assign(photons, photons + n);
+    s->pmMode = mode;
+    s->pmDepth = depth;
+    kd_build_all(*s);
+}
+void orc_gather_photons(const orc_scene* s, const float* points, const float* dirs, uint64_t n, rtgpu_photon_gather* out, int n_threads)
+{
+    parallel_for(n, n_threads, [&](uint64_t b, uint64_t e) {
+        for (uint64_t i = b; i < e; ++i) out[i] = gather_photons(*s, mk(points + 3 * i), mk(dirs + 3 * i));
+    });
 }
 
 float orc_triangle_area(const float a[3], const float b[3], const float c[3]) { return tri_area(mk(a), mk(b), mk(c)); }

@@ -31,6 +31,14 @@ typedef struct orc_scene orc_scene;
 orc_scene* orc_scene_create(const rtgpu_scene_desc* desc, int n_threads);
 void orc_scene_destroy(orc_scene* s);
 
+/* Photon map (the photonmapping directory): build by tracing (returns the photon count), transfer, and the gather of
+ * DiffuseMaterial.cpp:62-75; orc_render uses the scene's map. */
+uint64_t orc_build_photon_map(orc_scene* s, int32_t mode, int32_t depth, uint64_t rays_per_point_light, uint64_t rays_per_area_light,
+                              uint32_t seed, int n_threads);
+uint64_t orc_get_photons(const orc_scene* s, rtgpu_photon* out, uint64_t capacity);
+void orc_set_photons(orc_scene* s, const rtgpu_photon* photons, uint64_t n, int32_t mode, int32_t depth);
+void orc_gather_photons(const orc_scene* s, const float* points, const float* dirs, uint64_t n, rtgpu_photon_gather* out, int n_threads);
+
 /* Scene::traceRay per ray, reference traversal order and tie-breaks.  counts (optional):
  * 2 uint32 per ray {AABBs tested, triangles tested}. */
 void orc_trace_closest(const orc_scene* s, const float* o, const float* d, uint64_t n,

@@ -57,6 +57,19 @@ class Texture(C.Structure):
     _fields_ = [("rgba", c_u8_p), ("width", C.c_uint32), ("height", C.c_uint32), ("gamma", C.c_double)]
 
 
+class Photon(C.Structure):
+    _fields_ = [("pos", C.c_float * 3), ("normal", C.c_float * 3), ("energy", C.c_float * 3), ("is_caustic", C.c_uint32)]
+
+
+class PhotonGather(C.Structure):
+    _fields_ = [("count", C.c_uint32), ("max_dist", C.c_float), ("energy", C.c_float * 3)]
+
+
+PHOTON_DTYPE = np.dtype([("pos", np.float32, 3), ("normal", np.float32, 3), ("energy", np.float32, 3), ("is_caustic", np.uint32)])
+GATHER_DTYPE = np.dtype([("count", np.uint32), ("max_dist", np.float32), ("energy", np.float32, 3)])
+PM_NONE, PM_CAUSTICS, PM_FULL = 0, 1, 2
+
+
 class SceneDesc(C.Structure):
     _fields_ = [("meshes", C.POINTER(MeshDesc)), ("instances", C.POINTER(InstanceDesc)),
                 ("materials", C.POINTER(Material)), ("point_lights", C.POINTER(PointLight)),

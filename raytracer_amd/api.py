@@ -28,6 +28,7 @@ EXPORTS = [
     "rtgpu_scene_get_info", "rtgpu_trace_closest_count_device",
     "rtgpu_gltf_load", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
     "rtgpu_write_exr", "rtgpu_write_png",
+    "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
 ]
 
 _lib = None
@@ -73,6 +74,10 @@ def lib():
     L.rtgpu_camera_from_transform.argtypes = [C.c_double, C.POINTER(C.c_double), C.POINTER(abi.Camera)]
     L.rtgpu_scene_get_info.argtypes = [vp, C.POINTER(abi.SceneInfo)]
     L.rtgpu_trace_closest_count_device.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
+    L.rtgpu_scene_build_photon_map.argtypes = [vp, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint64)]
+    L.rtgpu_scene_get_photons.argtypes = [vp, vp, C.c_uint64, C.POINTER(C.c_uint64)]
+    L.rtgpu_scene_set_photons.argtypes = [vp, vp, C.c_uint64, C.c_int32, C.c_int32]
+    L.rtgpu_scene_gather_photons.argtypes = [vp, fp, fp, C.c_uint64, vp]
     L.rtgpu_write_exr.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_int]
     L.rtgpu_write_png.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_double, C.c_double]
     _lib = L
@@ -172,6 +177,35 @@ class Scene:
     def info(self) -> abi.SceneInfo:
         out = abi.SceneInfo()
         _check(lib().rtgpu_scene_get_info(self._h, C.byref(out)))
+        return out
+
+    # ---- photon map (photonmapping/PhotonMapBuilder.cpp:15-41, Scene::setPhotonMap) -------------
+    def build_photon_map(self, mode, depth, rays_per_point_light, rays_per_area_light, seed=0) -> int:
+        """Traces photons from every point and area light, builds the search structure and makes later renders
+        of this scene use it (the executable's --pmmode / --pmdepth / --pmrayspointlamp / --pmraysarealamp)."""
+        n = C.c_uint64()
+        _check(lib().rtgpu_scene_build_photon_map(self._h, int(mode), int(depth), int(rays_per_point_light), int(rays_per_area_light),
+                                                  int(seed), C.byref(n)))
+        return int(n.value)
+
+    def photons(self) -> np.ndarray:
+        n = C.c_uint64()
+        _check(lib().rtgpu_scene_get_photons(self._h, None, 0, C.byref(n)))
+        out = np.empty(int(n.value), dtype=abi.PHOTON_DTYPE)
+        if len(out):
+            _check(lib().rtgpu_scene_get_photons(self._h, out.ctypes.data_as(C.c_void_p), len(out), C.byref(n)))
+        return out
+
+    def set_photons(self, photons, mode, depth):
+        ph = np.ascontiguousarray(photons, dtype=abi.PHOTON_DTYPE)
+        _check(lib().rtgpu_scene_set_photons(self._h, ph.ctypes.data_as(C.c_void_p), len(ph), int(mode), int(depth)))
+
+    def gather_photons(self, points, dirs) -> np.ndarray:
+        """KDTree::getElementsNearestTo as the diffuse radiance estimate calls it (20 nearest, normal filter)."""
+        p, d = _f32(points), _f32(dirs)
+        out = np.empty(len(p), dtype=abi.GATHER_DTYPE)
+        _check(lib().rtgpu_scene_gather_photons(self._h, p.ctypes.data_as(abi.c_float_p), d.ctypes.data_as(abi.c_float_p), len(p),
+                                                out.ctypes.data_as(C.c_void_p)))
         return out
 
     # ---- Scene::traceRay / traceRays ---------------------------------------------------

@@ -165,26 +165,26 @@ int validate(const rtgpu_scene_desc* d)
 // IMaterial::hasVariance where it does not depend on the hit: 0 no, 1 yes, 2 hit-dependent
 // (DiffuseMaterial.cpp:228-247, GlossyMaterial.cpp:226-229, GlassMaterial.cpp:254-257, AddMaterial.cpp:25-28,
 // MixMaterial.cpp:59-65 with the constant factor of MixMaterial.h:19-26 narrowed to float)
-uint32_t material_variance(const rtgpu_scene_desc& d, uint32_t mi, int depth)
+uint32_t material_variance(const rtgpu_scene_desc& d, uint32_t mi, int depth, bool diffuseReadsMap = false)
 {
     const rtgpu_material& m = d.materials[mi];
     if (depth > 4) return 0;
     switch (m.type) {
-    case RTGPU_MAT_DIFFUSE: return 1;
+    case RTGPU_MAT_DIFFUSE: return diffuseReadsMap ? 0 : 1;
     case RTGPU_MAT_GLOSSY: return m.roughness > 0.0f ? 1 : 0;
     case RTGPU_MAT_GLASS: return 1;
     case RTGPU_MAT_ADD: {
-        const uint32_t a = material_variance(d, m.first, depth + 1), b = material_variance(d, m.second, depth + 1);
+        const uint32_t a = material_variance(d, m.first, depth + 1, diffuseReadsMap), b = material_variance(d, m.second, depth + 1, diffuseReadsMap);
         return (a == 1 || b == 1) ? 1 : ((a == 2 || b == 2) ? 2 : 0);
     }
     case RTGPU_MAT_CONSTMIX: {
         const float f = (float)m.mix_factor;
-        if (f == 0.0f) return material_variance(d, m.first, depth + 1);
-        if (f == 1.0f) return material_variance(d, m.second, depth + 1);
+        if (f == 0.0f) return material_variance(d, m.first, depth + 1, diffuseReadsMap);
+        if (f == 1.0f) return material_variance(d, m.second, depth + 1, diffuseReadsMap);
         return 1;
     }
     case RTGPU_MAT_FRESNELMIX: {
-        const uint32_t a = material_variance(d, m.first, depth + 1), b = material_variance(d, m.second, depth + 1);
+        const uint32_t a = material_variance(d, m.first, depth + 1, diffuseReadsMap), b = material_variance(d, m.second, depth + 1, diffuseReadsMap);
         return (a == 1 && b == 1) ? 1 : 2;
     }
     default: return 0;
@@ -208,7 +208,7 @@ void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
-                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd};
+                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.kdPos, view.kdNormal, view.kdEnergy};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
     view = rt::SceneView{};
@@ -468,7 +468,7 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         dm.texture = m.texture;
         dm.variance = material_variance(*desc, i, 0);
         dm.normalMap = m.normal_map;
-        dm.pad = 0;
+        dm.varianceMap = material_variance(*desc, i, 0, true);
         if (m.normal_map != 0) anyNormalMap = true;
     }
     // object -> world rows of every instance: the tangent of a normal-mapped hit is a world vector

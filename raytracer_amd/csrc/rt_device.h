@@ -18,7 +18,7 @@ struct DevMaterial {
     uint32_t texture;   // 1 + texture index (albedo / emission map), 0 = none
     uint32_t variance;  // IMaterial::hasVariance: 0 no, 1 yes, 2 depends on the hit (a Fresnel mix below decides)
     uint32_t normalMap; // 1 + texture index of a diffuse / glossy normal map, 0 = none
-    uint32_t pad;
+    uint32_t varianceMap; // `variance` for a vertex where diffuse closures read the photon map (they have no variance there)
 };
 
 struct DevTexture {
@@ -83,6 +83,14 @@ struct SceneView {
     int32_t hasGlass;           // some material is glass: paths carry the extra records of a glass vertex
     int32_t hasAdd;             // some material is an add material: paths carry a collected-emission record
     int32_t hasNormalMap;
+    // photon map (null / 0 without one): photons in search order (every range [lo, hi) has the median of its
+    // axis at lo + (hi - lo) / 2), xyz of position / surface normal / energy
+    const float4* kdPos;
+    const float4* kdNormal;
+    const float4* kdEnergy;
+    uint32_t nPhotons;
+    int32_t pmMode;             // rtgpu_photon_map_mode
+    int32_t pmDepth;
     float envRadiance[3];
 };
 

@@ -39,6 +39,8 @@
 #include "rt_scene.h"
 #include "rt_shade_inl.h"
 #include "rt_steal_inl.h"
+#include "rt_photon_inl.h"
+#include "rt_wave_inl.h"
 
 #ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256
@@ -56,6 +58,8 @@ constexpr uint32_t ST_RETRACE = 1u << 9;
 constexpr uint32_t ST_GLASS_PENDING = 1u << 10;   // a glass vertex waits for the hit of its own ray
 constexpr uint32_t ST_GLASS_INTERNAL = 1u << 11;  // ... and its transport direction points against the (flipped) normal
 constexpr uint32_t ST_GLASS_STICKY = 1u << 12;    // ... and a visibility query along its other direction is in flight
+constexpr uint32_t ST_DIFFUSE_SHIFT = 13;         // 4 bits: earlier vertices of the path with specularity < 0.8 (photon-map mode)
+constexpr uint32_t ST_DIFFUSE_MASK = 15u << ST_DIFFUSE_SHIFT;
 
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
@@ -86,7 +90,8 @@ struct Pool {
     uint32_t* qA;
     uint32_t* qB;
     uint32_t* qShadow;
-    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] unused, [3] prefix rays repeated per material sample
+    uint32_t* qPhoton;    // paths whose diffuse vertex reads the photon map (scenes with a photon map)
+    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] photon queue size, [3] prefix rays repeated per material sample
 };
 
 __device__ __forceinline__ float4 f4(float x, float y, float z, float w)
@@ -134,50 +139,24 @@ __device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool pre
     if (predS) qS[base[1] + cnt[1][wave] + (uint32_t)__popcll(mS & lt)] = value;
 }
 
-// Per-wave LDS of a traversal kernel: the work-stealing state for single-mesh scenes, the plain
-// per-lane stack otherwise.
-template <bool INSTANCED>
-struct TraceLds {
-    union type {   // per-lane stack (reference-order walk, scenes whose keys do not fit) or the cooperative state
-        int stack[kLdsStack][64];
-        StealLdsInst<false> coop;
-    };
-};
-template <>
-struct TraceLds<false> {
-    using type = StealLds<false>;
-};
-
-// Closest hit for the wave's rays (every lane calls; lanes without a ray pass has = false).
-template <bool INSTANCED>
-__device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool has, F3 o, F3 d, typename TraceLds<INSTANCED>::type& lds, int lane)
+// The same for one queue.
+template <int BLOCK>
+__device__ __forceinline__ void queue_push1(uint32_t* q, uint32_t* c, bool pred, uint32_t value)
 {
-    uint32_t nb = 0, nt = 0;
-    if constexpr (!INSTANCED) {
-        TraceResult r = trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
-        if (r.slot != kInvalid) hit_barycentrics(sv, r.slot, o, d, r.beta, r.gamma);
-        return r;
-    } else {
-        TraceResult r;
-        r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
-        if (sv.coopInstanced) return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
-        if (!has) return r;
-        if (sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, lds.stack, lane, nb, nt);
-        return trace_ray<true, false, false>(sv, o, d, INFINITY, lds.stack, lane, nb, nt);
+    constexpr int WAVES = BLOCK / 64;
+    __shared__ uint32_t cnt[WAVES];
+    __shared__ uint32_t base;
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    const unsigned long long m = __ballot(pred);
+    if (lane == 0) cnt[wave] = (uint32_t)__popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t total = 0;
+        for (int w = 0; w < WAVES; ++w) { const uint32_t k = cnt[w]; cnt[w] = total; total += k; }
+        base = total ? atomicAdd(c, total) : 0u;
     }
-}
-template <bool INSTANCED>
-__device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3 d, float tmax, typename TraceLds<INSTANCED>::type& lds, int lane)
-{
-    uint32_t nb = 0, nt = 0;
-    if constexpr (!INSTANCED) {
-        return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
-    } else {
-        if (sv.coopInstanced) return trace_wave_steal_inst<true, false>(sv, has, o, d, tmax, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
-        if (!has) return false;
-        if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);
-        return trace_ray<true, true, false>(sv, o, d, tmax, lds.stack, lane, nb, nt).inst != kInvalid;
-    }
+    __syncthreads();
+    if (pred) q[base + cnt[wave] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = value;
 }
 
 // ---- primary ---------------------------------------------------------------------------------
@@ -228,33 +207,10 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     pool.sC[s] = f4(__uint_as_float(r.slot), __uint_as_float(r.inst), r.beta, r.gamma);
 }
 
-// World-space shading normal of a hit: interpolated vertex normals (shape/TriangleMesh.cpp:114-120)
-// or the sphere's object-space hit point (shape/Sphere.cpp:52-53), then transformNormal + normalize
-// (shape/list/InstancedModelList.cpp:129-130, math/Transformation.h:95-99).
-__device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance& in, F3 wo, F3 wd, float t, uint32_t slot, float beta, float gamma)
-{
-    F3 objN;
-    if (slot != kInvalid) {
-        const float* vn = sv.vertNormals + (size_t)slot * 9;
-        const float alfa = 1.0f - beta - gamma;
-        const F3 na = f3(vn[0], vn[1], vn[2]), nb = f3(vn[3], vn[4], vn[5]), nc = f3(vn[6], vn[7], vn[8]);
-        objN = ((alfa * na) + (beta * nb)) + (gamma * nc);
-    } else {
-        const F3 oo = xf_point_inv(in.inv, wo), od = xf_vector_inv(in.inv, wd);
-        objN = oo + (t * od);
-    }
-    const double nx = objN.x, ny = objN.y, nz = objN.z;
-    const double* m = in.inv;
-    const F3 wn = f3((float)(((nx * m[0] + ny * m[4]) + nz * m[8]) + 0.0),
-                     (float)(((nx * m[1] + ny * m[5]) + nz * m[9]) + 0.0),
-                     (float)(((nx * m[2] + ny * m[6]) + nz * m[10]) + 0.0));
-    return normalized3(wn);
-}
-
 // ---- shade -----------------------------------------------------------------------------------
 // FIRST: the batch's first pass -- lane q is path q, vertex 0 is its sample's primary hit, and
 // nothing has been written for the path yet.  Otherwise lane q shades path qIn[q].
-// RICH: the scene has glass or add materials or normal maps (their code and registers are left out otherwise).
+// RICH: the scene has glass or add materials, normal maps or a photon map (their code and registers are left out otherwise).
 // A path's result is stored when the path ends here (black unless it collected something); a path
 // that goes on through a shadow ray gets black here and its contribution from the shadow stage.
 constexpr int kShadeBlock = RT_SHADE_BLOCK;
@@ -264,7 +220,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                                                     const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
 {
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
-    bool pushExt = false, pushShadow = false, repeated = false;
+    bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
     uint32_t p = 0;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     bool active = q < nIn;
@@ -447,7 +403,11 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             // the shading normal is needed up front only when a mix factor depends on the hit
             F3 normal = f3(0.0f, 0.0f, 0.0f);
             if (sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
-            const bool curVar = mat_has_variance(sv, mi, normal, d);
+            // PhotonMapMode::full: once `pmDepth` earlier vertices were diffuse, a diffuse closure reads the map
+            // (material/DiffuseMaterial.cpp:40-54) and has no variance (:228-247)
+            const uint32_t diffuseCount = (state & ST_DIFFUSE_MASK) >> ST_DIFFUSE_SHIFT;
+            const bool readsMap = RICH && sv.pmMode == RTGPU_PM_FULL && (int)diffuseCount >= sv.pmDepth;
+            const bool curVar = mat_has_variance(sv, mi, normal, d, readsMap);
             const bool isFirstVar = curVar && !passed;
             const int sampleCount = isFirstVar ? (int)M : 1;
             const int sampleI = isFirstVar ? (int)j : 0;
@@ -614,6 +574,18 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         writeThr = true;
                         pushExt = true;
                     }
+                } else if (RICH && mat.type == RTGPU_MAT_DIFFUSE && readsMap) {
+                    // the vertex ends the path with the map's radiance estimate (material/DiffuseMaterial.cpp:56-80,
+                    // 154-166); the gather stage adds it to what the path has collected
+                    done = true;
+                    completed = true;
+                    result = rgb_mul(thr, addE);
+                    o = hitpoint;
+                    outAux = f3(color.r, color.g, color.b);
+                    outAuxW = __uint_as_float(mi);
+                    writeAux = true;
+                    writeThr = true;
+                    pushPhoton = true;
                 } else if (mat.type == RTGPU_MAT_DIFFUSE) {
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;
@@ -654,6 +626,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             d = dir;
                             writeThr = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
+                            if (RICH && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity 0
                             pushExt = true;
                             done = true;
                         }
@@ -699,6 +672,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             outAux = hitpoint;
                             writeAux = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
+                            if (RICH && (1.0f - roughness) < 0.8 && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity = 1 - roughness
                             pushExt = true;
                         }
                     }
@@ -706,7 +680,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             }
         }
         repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
-        if (pushExt || pushShadow) {
+        if (pushExt || pushShadow || pushPhoton) {
             pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
             pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
             if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
@@ -722,6 +696,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
         }
     }
     queue_push2<kShadeBlock>(qExt, pool.counters + 0, pushExt, pool.qShadow, pool.counters + 1, pushShadow, p);
+    if (RICH) {
+        if (sv.pmMode == RTGPU_PM_FULL) queue_push1<kShadeBlock>(pool.qPhoton, pool.counters + 2, pushPhoton, p);   // uniform branch
+    }
     // Extension rays of vertices before the first variance vertex are identical for every material
     // sample j (the reference traces them once per geometry sample): count the repeats so that
     // the ray statistics only contain distinct rays.
@@ -774,6 +751,26 @@ __global__ __launch_bounds__(64) void trace_stage_kernel(SceneView sv, Pool pool
     const uint32_t extBlocks = (nExt + 63u) / 64u;
     if (blockIdx.x < extBlocks) extend_block<INSTANCED>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
     else shadow_block<INSTANCED>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
+}
+
+// ---- photon gather ----------------------------------------------------------------------------------
+// One lane per path whose diffuse vertex reads the photon map: photonLighting = sum of the 20 nearest photons'
+// energies * diffuseIntensity / (pi * maxDist^2) / pi, bsdf = diffuseColor * photonLighting
+// (material/DiffuseMaterial.cpp:62-75, 154-166), added to what the shade stage stored for the path.
+__global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, Pool pool, uint32_t n)
+{
+    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
+    if (q >= n) return;
+    const uint32_t p = pool.qPhoton[q];
+    const float4 ra = pool.rayA[p], rb = pool.rayB[p], au = pool.aux[p], tq = pool.thr[p], base = pool.result[p];
+    uint32_t count;
+    float maxDist;
+    RGBf value;
+    gather_photons(sv, f3(ra.x, ra.y, ra.z), f3(-rb.x, -rb.y, -rb.z), count, maxDist, value);
+    const DevMaterial& m = sv.materials[__float_as_uint(au.w)];
+    const RGBf photonLighting = rgb_div_d(rgb_div_d(rgb_scale_d(value, m.intensity), (RT_PI * maxDist) * maxDist), RT_PI);
+    const RGBf out = rgb_mul(rgb(tq.x, tq.y, tq.z), rgb_mul(rgb(au.x, au.y, au.z), photonLighting));
+    pool.result[p] = f4(base.x + out.r, base.y + out.g, base.z + out.b, 0.0f);
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
@@ -920,12 +917,13 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
         pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
         pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
+        pool.qPhoton = ws.alloc<uint32_t>(sv.pmMode == RTGPU_PM_FULL ? P : 1);
         pool.counters = ws.alloc<uint32_t>(4);
         if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
-        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap;
+        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode == RTGPU_PM_FULL;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
             Batch batch;
@@ -953,7 +951,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                 }
                 LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
                 LN_TRY(hipStreamSynchronize(ls));
-                const uint32_t nExt = h[0], nShadow = h[1], nRepeated = h[3];
+                const uint32_t nExt = h[0], nShadow = h[1], nPhoton = h[2], nRepeated = h[3];
+                if (nPhoton) hipLaunchKernelGGL(photon_gather_stage_kernel, dim3((nPhoton + 63) / 64), dim3(64), 0, ls, sv, pool, nPhoton);
                 if (nShadow || nExt) {
                     const uint32_t blocks = (nExt + 63) / 64 + (nShadow + 63) / 64;
                     if (single) hipLaunchKernelGGL((trace_stage_kernel<false>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);

@@ -1,0 +1,428 @@
+// rt_photon.hip -- the photon map on the GPU (gfx950): photon tracing, the search structure and the gather.
+//
+// Restates PhotonMapBuilder::buildPhotonMap (photonmapping/PhotonMapBuilder.cpp:15-41): PhotonTracer::tracePhotons
+// (photonmapping/PhotonTracer.cpp:8-172) with IMaterial::interactPhoton of every closure, and the query
+// KDTree::getElementsNearestTo as DiffuseMaterial uses it (photonmapping/KDTree.h:90-164,
+// material/DiffuseMaterial.cpp:62-75).
+//
+//   trace  : one lane per emitted ray, up to 12 vertices; every lane of a wave walks its photon through the
+//            scene with the wave-cooperative closest-hit query, so lanes whose photons left the scene still
+//            help the others.  A vertex that stores a photon writes slot [ray][vertex]; the host keeps the
+//            filled slots in (light, ray, vertex) order, so the map does not depend on scheduling.
+//   tree   : the reference sorts each slice along the next axis (y, z, x, ...) and takes the element at count / 2.
+//            The same tree is kept here without pointers: photons are permuted so that every range [lo, hi) has
+//            its axis median at lo + (hi - lo) / 2 (std::nth_element, host threads for the upper levels).
+//   gather : one lane per query point, depth-first with a stack of ranges in private memory and a bounded
+//            max-heap of the k best; the k nearest photons that pass the filter are the same set whatever the
+//            tree, distance ties aside.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rt_scene.h"
+#include "rt_photon_inl.h"
+#include "rt_wave_inl.h"
+
+namespace rt {
+
+namespace {
+
+constexpr uint32_t kPhotonPixel = 0x40000000u;  // RNG stream of photons: (seed, kPhotonPixel | light, ray, vertex, dim)
+constexpr uint32_t kVertexEmit = 254;
+constexpr int kMaxPhotonDepth = 12;              // PhotonDriver::trace, photonmapping/PhotonTracer.cpp:17
+constexpr uint32_t kEmptySlot = 0xFFFFFFFFu;
+
+struct EmitBatch {       // one task of PhotonTracer::tracePhotons
+    uint32_t light;      // index into the point or area lights
+    uint32_t area;       // 0: point light, 1: area light
+    uint32_t count;      // rays of the task (the stratification level of an area light)
+    uint32_t firstRay;   // ordinal of the task's first ray among the light's rays (RNG key)
+};
+
+// Rand::sampleStdNormalDist stand-in: Box-Muller on two uniform draws
+__device__ __forceinline__ float std_normal(float u1, float u2) { return (float)(sqrt(-2.0 * log(1.0 - (double)u1)) * cos(2.0 * RT_PI * (double)u2)); }
+
+// AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41
+__device__ __forceinline__ F3 area_point(const DevAreaLight& L, int level, int i, float r0, float r1)
+{
+    const int n = (int)sqrt((double)level);
+    const F3 a = f3(L.a[0], L.a[1], L.a[2]), b = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
+    const F3 v1 = (c - a) / (float)n;
+    const F3 v2 = (b - a) / (float)n;
+    const float u = 1.0f - sqrtf(r0);
+    const float v = (1.0f - u) * r1;
+    const int y = i / n;
+    const int x = i % n;
+    return (a + ((u + x) * v1)) + ((v + y) * v2);
+}
+
+// IMaterial::interactPhoton of the closures (Mix: MixMaterial.cpp:47-57, Add: AddMaterial.cpp:19-23, Diffuse:
+// DiffuseMaterial.cpp:206-226, Glossy: GlossyMaterial.cpp:209-224, Glass: GlassMaterial.cpp:180-252, Transparent:
+// TransparentMaterial.cpp:18-21, Emissive: EmissiveMaterial.cpp:24-27)
+__device__ void interact_photon(const SceneView& sv, uint32_t mi, uint32_t inst, uint32_t slot, float beta, float gamma, F3 normal, F3 rd, float t,
+                                RGBf incoming, uint32_t seed, uint32_t pixel, uint32_t ray, uint32_t vertex, F3& dir, RGBf& energy, float& diffuseness)
+{
+    for (uint32_t level = 0; level < 4; ++level) {
+        const DevMaterial& mm = sv.materials[mi];
+        if (mat_is_mix(mm)) mi = rand_unit(seed, pixel, ray, vertex, DIM_MIX0 + level) > mat_mix_factor(mm, normal, rd) ? mm.first : mm.second;
+        else if (mm.type == RTGPU_MAT_ADD) mi = mm.first;
+        else break;
+    }
+    const DevMaterial& m = sv.materials[mi];
+    F3 shadeN = normal;
+    if (m.normalMap != 0u && (m.type == RTGPU_MAT_DIFFUSE || m.type == RTGPU_MAT_GLOSSY)) shadeN = sample_normal_map(sv, m.normalMap - 1u, inst, slot, beta, gamma, normal);
+    if (m.type == RTGPU_MAT_DIFFUSE) {
+        RGBf color = rgb(m.color[0], m.color[1], m.color[2]);
+        if (m.texture != 0u) {
+            float tu, tv;
+            hit_texcoord(sv, slot, beta, gamma, tu, tv);
+            color = emission_lookup(sv, m.texture - 1u, tu, tv);   // the abs(fmod) wrap of DiffuseMaterial.cpp:211-212
+        }
+        const Basis3 basis = basis_from(shadeN);
+        const F3 l = cosine_hemisphere(rand_unit(seed, pixel, ray, vertex, DIM_SQUARE_X), rand_unit(seed, pixel, ray, vertex, DIM_SQUARE_Y));
+        dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
+        energy = rgb_mul(color, incoming);
+        diffuseness = 1.0f;
+    } else if (m.type == RTGPU_MAT_GLOSSY) {
+        const F3 micro = normalized3(vndf_sample(shadeN, -rd, m.roughness, rand_unit(seed, pixel, ray, vertex, DIM_SQUARE_X), rand_unit(seed, pixel, ray, vertex, DIM_SQUARE_Y)));
+        dir = rd + ((float)(2.0 * (double)dot3(micro, -rd)) * micro);
+        energy = incoming;
+        diffuseness = m.roughness;
+    } else if (m.type == RTGPU_MAT_GLASS) {
+        F3 n = normal;
+        const bool attenuate = dot3(n, rd) < 0;
+        const F3 objToIncoming = -rd;
+        const F3 reflDir = (-objToIncoming) + ((float)(2.0 * (double)dot3(n, objToIncoming)) * n);
+        double nDotWo = dot3(n, objToIncoming);
+        double incomingAngle = nDotWo;
+        const bool internal = nDotWo < 0;
+        double curRelIor = m.intensity / 1.0;
+        if (internal) curRelIor = 1.0 / curRelIor;
+        const double cosTransmissionSqr = 1.0 - ((1.0 - (incomingAngle * incomingAngle)) / (curRelIor * curRelIor));
+        if (cosTransmissionSqr < 0) {
+            dir = reflDir;
+        } else {
+            if (internal) { nDotWo = -nDotWo; incomingAngle = -incomingAngle; n = -n; }
+            const double cosRefractAngle = sqrt(cosTransmissionSqr);
+            const F3 transDir = (rd / (float)curRelIor) - ((float)(cosRefractAngle - (incomingAngle / curRelIor)) * n);
+            const double rs = ((curRelIor * nDotWo) - cosRefractAngle) / ((curRelIor * nDotWo) + cosRefractAngle);
+            const double rp = (nDotWo - (curRelIor * cosRefractAngle)) / (nDotWo + (curRelIor * cosRefractAngle));
+            const double kr = ((rs * rs) + (rp * rp)) / 2.0;
+            const double reflectionWeight = kr / (kr + (1.0 - kr));
+            dir = (double)rand_unit(seed, pixel, ray, vertex, DIM_GLASS) < reflectionWeight ? reflDir : transDir;
+        }
+        energy = incoming;
+        if (attenuate) energy = rgb_mul(incoming, rgb_pow_d(rgb(m.color[0], m.color[1], m.color[2]), (double)m.roughness * (double)t));
+        diffuseness = 0.0f;
+    } else if (m.type == RTGPU_MAT_TRANSPARENT) {
+        dir = rd; energy = incoming; diffuseness = 0.0f;
+    } else {
+        dir = -rd; energy = rgb(0, 0, 0); diffuseness = 0.0f;
+    }
+}
+
+// One lane per ray of the launch; batchStart[b] is the launch-local index of batch b's first ray.
+template <bool INSTANCED>
+__global__ __launch_bounds__(64) void photon_trace_kernel(SceneView sv, const EmitBatch* __restrict__ batches, const uint32_t* __restrict__ batchStart,
+                                                          uint32_t nBatches, uint32_t nRays, int mode, double perPoint, float perArea, uint32_t seed,
+                                                          rtgpu_photon* __restrict__ slots)
+{
+    __shared__ typename TraceLds<INSTANCED>::type lds;
+    const int lane = threadIdx.x;
+    const uint32_t r = blockIdx.x * 64u + lane;
+    bool alive = r < nRays;
+    F3 o = f3(0, 0, 0), d = f3(0, 0, 1);
+    RGBf energy = rgb(0, 0, 0);
+    uint32_t pixel = 0, ray = 0;
+    if (alive) {
+        // the batch of this ray: last batch whose start is <= r
+        uint32_t lo = 0, hi = nBatches;
+        while (hi - lo > 1) { const uint32_t mid = (lo + hi) / 2; if (batchStart[mid] <= r) lo = mid; else hi = mid; }
+        const EmitBatch b = batches[lo];
+        const uint32_t k = r - batchStart[lo];
+        ray = b.firstRay + k;
+        if (!b.area) { // PointLightPhotonTracingTask::execute, photonmapping/PhotonTracer.cpp:84-96
+            const DevPointLight& L = sv.pointLights[b.light];
+            pixel = kPhotonPixel | b.light;
+            energy = rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity / perPoint);
+            const float x = std_normal(rand_unit(seed, pixel, ray, kVertexEmit, 0), rand_unit(seed, pixel, ray, kVertexEmit, 1));
+            const float y = std_normal(rand_unit(seed, pixel, ray, kVertexEmit, 2), rand_unit(seed, pixel, ray, kVertexEmit, 3));
+            const float z = std_normal(rand_unit(seed, pixel, ray, kVertexEmit, 4), rand_unit(seed, pixel, ray, kVertexEmit, 5));
+            const float len = sqrtf(x * x + y * y + z * z);   // sampleUniformSphere(1.0), math/Sampler.h:42-49
+            o = f3(L.pos[0], L.pos[1], L.pos[2]);
+            d = f3(1.0f * x / len, 1.0f * y / len, 1.0f * z / len);
+        } else {       // AreaLightPhotonTracingTask::execute, :121-137
+            const DevAreaLight& L = sv.areaLights[b.light];
+            pixel = kPhotonPixel | (sv.nPointLights + b.light);
+            energy = rgb_div_f(rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity), perArea);
+            const F3 a = f3(L.a[0], L.a[1], L.a[2]), bb = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
+            const Basis3 basis = basis_from(cross3(bb - a, c - a));
+            const F3 pos = area_point(L, (int)b.count, (int)k, rand_unit(seed, pixel, ray, kVertexEmit, DIM_AREA_U), rand_unit(seed, pixel, ray, kVertexEmit, DIM_AREA_V));
+            const F3 l = cosine_hemisphere(rand_unit(seed, pixel, ray, kVertexEmit, DIM_SQUARE_X), rand_unit(seed, pixel, ray, kVertexEmit, DIM_SQUARE_Y));
+            d = normalized3(((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z));
+            o = pos + (d * 0.0001f);
+        }
+    }
+    bool hasPassedSpecular = false;
+    for (int v = 0; v < kMaxPhotonDepth; ++v) {   // PhotonDriver::trace, :12-58
+        if (__ballot(alive) == 0ull) break;
+        const TraceResult hr = wave_closest<INSTANCED>(sv, alive, o, d, lds, lane);
+        if (!alive) continue;
+        if (hr.inst == kInvalid) { alive = false; continue; }
+        const DevInstance& in = sv.inst[hr.inst];
+        uint32_t mi = in.material;
+        if (hr.slot != kInvalid && sv.triMaterial) {
+            const uint32_t tm = sv.triMaterial[hr.slot];
+            if (tm != kInvalid) mi = tm;
+        }
+        const F3 hitpoint = o + (d * hr.t);
+        const F3 normal = hit_normal(sv, in, o, d, hr.t, hr.slot, hr.beta, hr.gamma);
+        F3 newDir;
+        RGBf newEnergy;
+        float diffuseness;
+        interact_photon(sv, mi, hr.inst, hr.slot, hr.beta, hr.gamma, normal, d, hr.t, energy, seed, pixel, ray, (uint32_t)v, newDir, newEnergy, diffuseness);
+        newDir = normalized3(newDir);
+        const bool isDiffuseTransport = diffuseness >= 0.2;
+        const bool isCaustic = isDiffuseTransport && hasPassedSpecular;
+        if ((mode == RTGPU_PM_CAUSTICS && isCaustic) || (mode == RTGPU_PM_FULL && isDiffuseTransport)) {
+            rtgpu_photon ph;
+            ph.pos[0] = hitpoint.x; ph.pos[1] = hitpoint.y; ph.pos[2] = hitpoint.z;
+            ph.normal[0] = normal.x; ph.normal[1] = normal.y; ph.normal[2] = normal.z;
+            ph.energy[0] = energy.r; ph.energy[1] = energy.g; ph.energy[2] = energy.b;
+            ph.is_caustic = isCaustic ? 1u : 0u;
+            slots[(size_t)r * kMaxPhotonDepth + v] = ph;
+        }
+        hasPassedSpecular = hasPassedSpecular || !isDiffuseTransport;
+        o = hitpoint + (newDir * 0.00005f);
+        d = newDir;
+        energy = newEnergy;
+    }
+}
+
+__global__ void fill_empty_kernel(rtgpu_photon* slots, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) slots[i].is_caustic = kEmptySlot;
+}
+
+} // namespace
+
+namespace {
+
+__global__ __launch_bounds__(64) void gather_kernel(SceneView sv, const float* __restrict__ points, const float* __restrict__ dirs, uint64_t n,
+                                                   rtgpu_photon_gather* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x;
+    if (i >= n) return;
+    uint32_t count;
+    float maxDist;
+    RGBf sum;
+    gather_photons(sv, f3(points[3 * i], points[3 * i + 1], points[3 * i + 2]), f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), count, maxDist, sum);
+    rtgpu_photon_gather g;
+    g.count = count; g.max_dist = maxDist; g.energy[0] = sum.r; g.energy[1] = sum.g; g.energy[2] = sum.b;
+    out[i] = g;
+}
+
+// Permutes idx[lo, hi) so that every range has its median along axis (depth + 1) % 3 in the middle.
+void kd_order(const std::vector<rtgpu_photon>& ph, uint32_t* idx, size_t lo, size_t hi, uint32_t depth, int spawnLevels)
+{
+    while (hi - lo > 1) {
+        const size_t mid = lo + (hi - lo) / 2;
+        const int axis = (int)((depth + 1u) % 3u);
+        std::nth_element(idx + lo, idx + mid, idx + hi, [&](uint32_t a, uint32_t b) { return ph[a].pos[axis] < ph[b].pos[axis]; });
+        if (spawnLevels > 0 && hi - lo > 100000) {
+            std::thread left([&, lo, mid, depth, spawnLevels] { kd_order(ph, idx, lo, mid, depth + 1, spawnLevels - 1); });
+            kd_order(ph, idx, mid + 1, hi, depth + 1, spawnLevels - 1);
+            left.join();
+            return;
+        }
+        kd_order(ph, idx, lo, mid, depth + 1, 0);
+        lo = mid + 1;
+        depth += 1;
+    }
+}
+
+struct Dev {
+    void* p = nullptr;
+    ~Dev() { if (p) (void)hipFree(p); }
+};
+
+#define PH_HIP(call)                                                                                   \
+    do {                                                                                               \
+        hipError_t e_ = (call);                                                                        \
+        if (e_ != hipSuccess) return set_error(RTGPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+} // namespace
+
+// Uploads the search structure for scene.photons and switches the scene to (mode, depth).
+int install_photon_map(rtgpu_scene& scene, int mode, int depth)
+{
+    SceneView& v = scene.view;
+    PH_HIP(hipSetDevice(scene.device));
+    for (const void* p : {(const void*)v.kdPos, (const void*)v.kdNormal, (const void*)v.kdEnergy})
+        if (p) (void)hipFree(const_cast<void*>(p));
+    v.kdPos = v.kdNormal = v.kdEnergy = nullptr;
+    v.nPhotons = 0;
+    v.pmMode = RTGPU_PM_NONE;
+    v.pmDepth = 0;
+    const std::vector<rtgpu_photon>& ph = scene.photons;
+    if (mode == RTGPU_PM_NONE) return RTGPU_OK;
+    if (ph.size() >= (1ull << 31)) return set_error(RTGPU_ERR_LIMIT, "more than 2^31 photons");
+    const size_t n = ph.size();
+    if (n) {
+        std::vector<uint32_t> idx(n);
+        for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
+        kd_order(ph, idx.data(), 0, n, 0, 4);
+        std::vector<float4> pos(n), nrm(n), en(n);
+        for (size_t i = 0; i < n; ++i) {
+            const rtgpu_photon& p = ph[idx[i]];
+            pos[i] = make_float4(p.pos[0], p.pos[1], p.pos[2], 0.0f);
+            nrm[i] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.0f);
+            en[i] = make_float4(p.energy[0], p.energy[1], p.energy[2], 0.0f);
+        }
+        void *dp = nullptr, *dn = nullptr, *de = nullptr;
+        PH_HIP(hipMalloc(&dp, n * sizeof(float4)));
+        v.kdPos = (const float4*)dp;
+        PH_HIP(hipMalloc(&dn, n * sizeof(float4)));
+        v.kdNormal = (const float4*)dn;
+        PH_HIP(hipMalloc(&de, n * sizeof(float4)));
+        v.kdEnergy = (const float4*)de;
+        PH_HIP(hipMemcpy(dp, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dn, nrm.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(de, en.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+    }
+    v.nPhotons = (uint32_t)n;
+    v.pmMode = mode;
+    v.pmDepth = depth;
+    return RTGPU_OK;
+}
+
+int trace_photons(rtgpu_scene& scene, int mode, uint64_t perPoint, uint64_t perArea, uint32_t seed)
+{
+    const SceneView& sv = scene.view;
+    scene.photons.clear();
+    if (mode == RTGPU_PM_NONE) return RTGPU_OK;
+    PH_HIP(hipSetDevice(scene.device));
+    // the tasks of PhotonTracer::tracePhotons (:139-172): createBatches (utility/Batcher.h) cuts photonsPerPointLight
+    // rays -- for area lights too -- into batches of 10 000 and issues a last partial batch twice
+    std::vector<EmitBatch> batches;
+    const uint64_t batchSize = 10000;
+    if (perPoint >= (1ull << 31)) return set_error(RTGPU_ERR_LIMIT, "more than 2^31 rays per light");
+    auto add = [&](uint32_t light, uint32_t area) {
+        uint64_t ray = 0;
+        for (uint64_t i = 0; i < perPoint; i += batchSize) {
+            const uint64_t e = std::min(i + batchSize, perPoint);
+            batches.push_back(EmitBatch{light, area, (uint32_t)(e - i), (uint32_t)ray});
+            ray += e - i;
+        }
+        const uint64_t rem = perPoint % batchSize;
+        if (rem > 0) batches.push_back(EmitBatch{light, area, (uint32_t)rem, (uint32_t)ray});
+    };
+    for (uint32_t l = 0; l < sv.nPointLights; ++l) add(l, 0u);
+    for (uint32_t l = 0; l < sv.nAreaLights; ++l) add(l, 1u);
+    if (batches.empty()) return RTGPU_OK;
+    // launches of at most 100 batches (1 M rays, 480 MB of slots)
+    const size_t perLaunch = 100;
+    Dev dSlots, dBatches, dStarts;
+    const size_t slotCap = perLaunch * batchSize * kMaxPhotonDepth;
+    PH_HIP(hipMalloc(&dSlots.p, slotCap * sizeof(rtgpu_photon)));
+    PH_HIP(hipMalloc(&dBatches.p, perLaunch * sizeof(EmitBatch)));
+    PH_HIP(hipMalloc(&dStarts.p, perLaunch * sizeof(uint32_t)));
+    std::vector<rtgpu_photon> host;
+    for (size_t b0 = 0; b0 < batches.size(); b0 += perLaunch) {
+        const size_t nb = std::min(perLaunch, batches.size() - b0);
+        std::vector<uint32_t> starts(nb);
+        uint32_t nRays = 0;
+        for (size_t b = 0; b < nb; ++b) { starts[b] = nRays; nRays += batches[b0 + b].count; }
+        const size_t nSlots = (size_t)nRays * kMaxPhotonDepth;
+        PH_HIP(hipMemcpy(dBatches.p, batches.data() + b0, nb * sizeof(EmitBatch), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dStarts.p, starts.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, nullptr, (rtgpu_photon*)dSlots.p, nSlots);
+        if (sv.singleMesh)
+            hipLaunchKernelGGL((photon_trace_kernel<false>), dim3((nRays + 63) / 64), dim3(64), 0, nullptr, sv, (const EmitBatch*)dBatches.p,
+                               (const uint32_t*)dStarts.p, (uint32_t)nb, nRays, mode, (double)perPoint, (float)perArea, seed, (rtgpu_photon*)dSlots.p);
+        else
+            hipLaunchKernelGGL((photon_trace_kernel<true>), dim3((nRays + 63) / 64), dim3(64), 0, nullptr, sv, (const EmitBatch*)dBatches.p,
+                               (const uint32_t*)dStarts.p, (uint32_t)nb, nRays, mode, (double)perPoint, (float)perArea, seed, (rtgpu_photon*)dSlots.p);
+        PH_HIP(hipGetLastError());
+        host.resize(nSlots);
+        PH_HIP(hipMemcpy(host.data(), dSlots.p, nSlots * sizeof(rtgpu_photon), hipMemcpyDeviceToHost));
+        for (const rtgpu_photon& p : host)
+            if (p.is_caustic != kEmptySlot) scene.photons.push_back(p);
+    }
+    return RTGPU_OK;
+}
+
+int gather_photons_host(const rtgpu_scene& scene, const float* points, const float* dirs, uint64_t n, rtgpu_photon_gather* out)
+{
+    PH_HIP(hipSetDevice(scene.device));
+    const uint64_t cap = std::min<uint64_t>(n, 1ull << 22);
+    Dev dP, dD, dO;
+    PH_HIP(hipMalloc(&dP.p, cap * 12));
+    PH_HIP(hipMalloc(&dD.p, cap * 12));
+    PH_HIP(hipMalloc(&dO.p, cap * sizeof(rtgpu_photon_gather)));
+    for (uint64_t b = 0; b < n; b += cap) {
+        const uint64_t m = std::min(cap, n - b);
+        PH_HIP(hipMemcpy(dP.p, points + 3 * b, m * 12, hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
+        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, nullptr, scene.view, (const float*)dP.p, (const float*)dD.p, m,
+                           (rtgpu_photon_gather*)dO.p);
+        PH_HIP(hipGetLastError());
+        PH_HIP(hipMemcpy(out + b, dO.p, m * sizeof(rtgpu_photon_gather), hipMemcpyDeviceToHost));
+    }
+    return RTGPU_OK;
+}
+
+} // namespace rt
+
+extern "C" {
+
+int rtgpu_scene_build_photon_map(rtgpu_scene* scene, int32_t mode, int32_t depth, uint64_t rays_per_point_light, uint64_t rays_per_area_light,
+                                 uint32_t seed, uint64_t* n_photons)
+{
+    if (!scene) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (mode < RTGPU_PM_NONE || mode > RTGPU_PM_FULL) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "unknown photon map mode");
+    if (depth < 0 || depth > 15) return rt::set_error(RTGPU_ERR_LIMIT, "photon map depth must be 0..15");
+    if (mode != RTGPU_PM_NONE && (rays_per_point_light == 0 || rays_per_area_light == 0))
+        return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "Invalid PM raycount settings!");   // exe/Raytracer.cpp:237-241
+    if (int rc = rt::trace_photons(*scene, mode, rays_per_point_light, rays_per_area_light, seed)) return rc;
+    if (n_photons) *n_photons = scene->photons.size();
+    return rt::install_photon_map(*scene, mode, depth);
+}
+
+int rtgpu_scene_get_photons(const rtgpu_scene* scene, rtgpu_photon* out, uint64_t capacity, uint64_t* n)
+{
+    if (!scene) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    const uint64_t m = std::min<uint64_t>(capacity, scene->photons.size());
+    if (m && !out) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "null photon buffer");
+    if (m) std::memcpy(out, scene->photons.data(), m * sizeof(rtgpu_photon));
+    if (n) *n = scene->photons.size();
+    return RTGPU_OK;
+}
+
+int rtgpu_scene_set_photons(rtgpu_scene* scene, const rtgpu_photon* photons, uint64_t n, int32_t mode, int32_t depth)
+{
+    if (!scene) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (mode < RTGPU_PM_NONE || mode > RTGPU_PM_FULL) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "unknown photon map mode");
+    if (depth < 0 || depth > 15) return rt::set_error(RTGPU_ERR_LIMIT, "photon map depth must be 0..15");
+    if (n && !photons) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "null photon buffer");
+    scene->photons.assign(photons, photons + n);
+    return rt::install_photon_map(*scene, mode, depth);
+}
+
+int rtgpu_scene_gather_photons(const rtgpu_scene* scene, const float* points, const float* directions, uint64_t n, rtgpu_photon_gather* out)
+{
+    if (!scene) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (n == 0) return RTGPU_OK;
+    if (!points || !directions || !out) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "null query/result buffer");
+    return rt::gather_photons_host(*scene, points, directions, n, out);
+}
+
+} // extern "C"

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <string>
+#include <vector>
 
 #include "../../include/rtgpu.h"
 #include "rt_device.h"
@@ -11,6 +12,7 @@ struct rtgpu_scene {
     int device = 0;
     rt::SceneView view{};
     rtgpu_scene_info info{};
+    std::vector<rtgpu_photon> photons;   // the photon map's photons in emission order (host copy)
     void release();
 };
 

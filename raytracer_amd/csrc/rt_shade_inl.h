@@ -360,24 +360,27 @@ __device__ __forceinline__ float mat_mix_factor(const DevMaterial& M, F3 normal,
 // materials where it does not depend on the hit (0 / 1); 2 = a Fresnel mix decides per hit.  Mix and
 // add materials nest at most 4 deep (checked at scene creation), so the recursion is unrolled.
 template <int DEPTH>
-__device__ __forceinline__ bool mat_variance_at(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir)
+__device__ __forceinline__ bool mat_variance_at(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir, bool diffuseReadsMap)
 {
     const DevMaterial& M = sv.materials[mi];
-    if (M.variance != 2u) return M.variance != 0u;
+    const uint32_t cls = diffuseReadsMap ? M.varianceMap : M.variance;
+    if (cls != 2u) return cls != 0u;
     if constexpr (DEPTH == 0) {
         return false;
     } else {
         if (M.type == RTGPU_MAT_ADD)
-            return mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir) || mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir);
+            return mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir, diffuseReadsMap) || mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir, diffuseReadsMap);
         const float f = mat_mix_factor(M, normal, incomingDir);
-        const bool noVar = (f == 0.0f && !mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir)) ||
-                           (f == 1.0f && !mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir));
+        const bool noVar = (f == 0.0f && !mat_variance_at<DEPTH - 1>(sv, M.first, normal, incomingDir, diffuseReadsMap)) ||
+                           (f == 1.0f && !mat_variance_at<DEPTH - 1>(sv, M.second, normal, incomingDir, diffuseReadsMap));
         return !noVar;
     }
 }
-__device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir)
+// diffuseReadsMap: the path is at a vertex where a diffuse closure reads the photon map instead of sampling
+// (PhotonMapMode::full, DiffuseMaterial.cpp:228-247) and therefore has no variance
+__device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t mi, F3 normal, F3 incomingDir, bool diffuseReadsMap = false)
 {
-    return mat_variance_at<4>(sv, mi, normal, incomingDir);
+    return mat_variance_at<4>(sv, mi, normal, incomingDir, diffuseReadsMap);
 }
 
 __device__ __forceinline__ RGBf rgb_add(RGBf a, RGBf b) { return RGBf{a.r + b.r, a.g + b.g, a.b + b.b}; } // RGB::operator+, film/RGB.h:93-105

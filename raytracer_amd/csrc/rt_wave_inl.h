@@ -1,0 +1,80 @@
+// rt_wave_inl.h -- what the kernels of the integrator and of the photon tracer share: closest / any hit for the
+// rays of one wave (cooperative traversal where the scene allows it) and the shading normal of a hit.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "rt_shade_inl.h"
+#include "rt_steal_inl.h"
+
+namespace rt {
+
+// Per-wave LDS of a traversal kernel: the work-stealing state for single-mesh scenes, the plain
+// per-lane stack otherwise.
+template <bool INSTANCED>
+struct TraceLds {
+    union type {   // per-lane stack (reference-order walk, scenes whose keys do not fit) or the cooperative state
+        int stack[kLdsStack][64];
+        StealLdsInst<false> coop;
+    };
+};
+template <>
+struct TraceLds<false> {
+    using type = StealLds<false>;
+};
+
+// Closest hit for the wave's rays (every lane calls; lanes without a ray pass has = false).
+template <bool INSTANCED>
+__device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool has, F3 o, F3 d, typename TraceLds<INSTANCED>::type& lds, int lane)
+{
+    uint32_t nb = 0, nt = 0;
+    if constexpr (!INSTANCED) {
+        TraceResult r = trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+        if (r.slot != kInvalid) hit_barycentrics(sv, r.slot, o, d, r.beta, r.gamma);
+        return r;
+    } else {
+        TraceResult r;
+        r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
+        if (sv.coopInstanced) return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
+        if (!has) return r;
+        if (sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, lds.stack, lane, nb, nt);
+        return trace_ray<true, false, false>(sv, o, d, INFINITY, lds.stack, lane, nb, nt);
+    }
+}
+template <bool INSTANCED>
+__device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3 d, float tmax, typename TraceLds<INSTANCED>::type& lds, int lane)
+{
+    uint32_t nb = 0, nt = 0;
+    if constexpr (!INSTANCED) {
+        return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
+    } else {
+        if (sv.coopInstanced) return trace_wave_steal_inst<true, false>(sv, has, o, d, tmax, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
+        if (!has) return false;
+        if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);
+        return trace_ray<true, true, false>(sv, o, d, tmax, lds.stack, lane, nb, nt).inst != kInvalid;
+    }
+}
+
+// World-space shading normal of a hit: interpolated vertex normals (shape/TriangleMesh.cpp:114-120)
+// or the sphere's object-space hit point (shape/Sphere.cpp:52-53), then transformNormal + normalize
+// (shape/list/InstancedModelList.cpp:129-130, math/Transformation.h:95-99).
+__device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance& in, F3 wo, F3 wd, float t, uint32_t slot, float beta, float gamma)
+{
+    F3 objN;
+    if (slot != kInvalid) {
+        const float* vn = sv.vertNormals + (size_t)slot * 9;
+        const float alfa = 1.0f - beta - gamma;
+        const F3 na = f3(vn[0], vn[1], vn[2]), nb = f3(vn[3], vn[4], vn[5]), nc = f3(vn[6], vn[7], vn[8]);
+        objN = ((alfa * na) + (beta * nb)) + (gamma * nc);
+    } else {
+        const F3 oo = xf_point_inv(in.inv, wo), od = xf_vector_inv(in.inv, wd);
+        objN = oo + (t * od);
+    }
+    const double nx = objN.x, ny = objN.y, nz = objN.z;
+    const double* m = in.inv;
+    const F3 wn = f3((float)(((nx * m[0] + ny * m[4]) + nz * m[8]) + 0.0),
+                     (float)(((nx * m[1] + ny * m[5]) + nz * m[9]) + 0.0),
+                     (float)(((nx * m[2] + ny * m[6]) + nz * m[10]) + 0.0));
+    return normalized3(wn);
+}
+
+} // namespace rt
