@@ -291,8 +291,9 @@ int rtgpu_trace_closest_count_device(const rtgpu_scene* scene, const float* d_or
 
 /* PhotonMapMode (scene/renderable/Scene.h) as the executable's --pmmode sets it.  "full": a diffuse vertex reads
  * the map instead of sampling once `depth` earlier vertices of its path were diffuse (specularity < 0.8),
- * material/DiffuseMaterial.cpp:39-80.  "caustics" (DiffuseMaterial.cpp:104-135, GlassMaterial.cpp:31-38) is
- * accepted by the photon tracer only (it selects which photons are stored); rendering with it is not built. */
+ * material/DiffuseMaterial.cpp:39-80.  "caustics": only photons that arrive after a specular bounce are stored; a
+ * diffuse bounce whose next vertex turns out specular ends the path with the map's estimate instead, and glass
+ * behind a diffuse or rough bounce is black (DiffuseMaterial.cpp:104-135, GlassMaterial.cpp:31-38). */
 typedef enum rtgpu_photon_map_mode {
     RTGPU_PM_NONE = 0,
     RTGPU_PM_CAUSTICS = 1,

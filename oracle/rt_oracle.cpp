@@ -1172,6 +1172,7 @@ struct TransportNode { // material/IMaterial.h:17-30 + the per-material Transpor
     int lightHit = -1;         // GlossyMaterial, index into areaLights
     float specularity = 0;     // TransportNode::specularity (IMaterial.h:23): what DiffuseMaterial counts in photon-map mode
     bool isPhotonMapRay = false; // DiffuseMaterial: the vertex reads the photon map
+    bool typeBounce = true;    // TransportNode::type == TransportType::bounce (IMaterial.h:12-15, 24)
     RGBf photonLighting;
     // GlassMaterial's TransportMetaData (material/GlassMaterial.cpp:11-18).  The reference keeps metadata in
     // a tree with one slot per MixMaterial branch (utility/DynAllocTree.h:118-131: depth 3, two children),
@@ -1264,6 +1265,7 @@ struct SampleOut {
     bool hasNextHit = false;
     SceneHit nextHit;
     bool tracedMiss = false;   // the material traced the ray samplePath would trace (same origin) and it left the scene
+    bool causticsCallback = false;   // DiffuseMaterial left a nextNodeCallback (material/DiffuseMaterial.cpp:104-135)
 };
 
 // Triangle::intersect against every area light (renderer/Renderer.cpp:184-204, GlossyMaterial.cpp:126-178)
@@ -1337,6 +1339,13 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         if (!meta.used) {
             meta = TransportNode::GlassMeta{};
             meta.used = true;
+            // caustics mode: behind a diffuse or rough bounce the photon map supplies what would pass the glass (:31-38)
+            if (S.pmMode == RTGPU_PM_CAUSTICS && R.curI != 0 && (*R.path)[R.curI - 1].specularity < 0.8 && (*R.path)[R.curI - 1].typeBounce) {
+                tn.isEmissive = true;
+                tn.pathTerminationChance = 1.0f;
+                meta.reflectionWeight = NAN;
+                return;
+            }
             tn.isEmissive = false;
             tn.pathTerminationChance = 0.1f;
             V3& normal = tn.hit.normal;   // the reference flips the node's normal in place (:45, :77)
@@ -1353,6 +1362,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
             if (tir) {
                 meta.reflectionWeight = 1.0;
                 meta.t = NAN;
+                tn.typeBounce = true;
                 tn.transportDirection = meta.reflectedRayDir;
                 return;
             }
@@ -1371,7 +1381,8 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
             double totalWeight = reflectionWeight + transmissionWeight;
             meta.reflectionWeight = (float)(reflectionWeight / totalWeight);
         }
-        tn.transportDirection = rc.unit(DIM_GLASS) < meta.reflectionWeight ? meta.reflectedRayDir : meta.transmittedRayDir;
+        tn.typeBounce = rc.unit(DIM_GLASS) < meta.reflectionWeight;
+        tn.transportDirection = tn.typeBounce ? meta.reflectedRayDir : meta.transmittedRayDir;
         V3 hitpoint = tn.hit.hitpoint();
         V3 ro = hitpoint + (tn.transportDirection * 0.0001f);
         R.extension++;
@@ -1397,6 +1408,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
     case RTGPU_MAT_TRANSPARENT: // TransparentMaterial::sampleTransport, material/TransparentMaterial.cpp:3-11
         tn.leafMat = mi;
         tn.specularity = 1.0f;
+        tn.typeBounce = true;
         tn.isEmissive = false;
         tn.pathTerminationChance = 0.01;
         tn.transportDirection = tn.hit.rd;
@@ -1410,6 +1422,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         tn.leafMat = mi;
         V3 normal = shading_normal(S, m, tn.hit);
         tn.specularity = 0.0f;
+        tn.typeBounce = true;
         tn.isPhotonMapRay = false;
         if (diffuse_reads_map(S, *R.path, R.curI)) { // material/DiffuseMaterial.cpp:56-80
             tn.pathTerminationChance = 1.0f;
@@ -1436,6 +1449,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
             V3 l = cosine_hemisphere(sx, sy);
             tn.transportDirection = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
             tn.isNEERay = false;
+            if (S.pmMode == RTGPU_PM_CAUSTICS) out.causticsCallback = true;
         }
         return;
     }
@@ -1445,6 +1459,7 @@ void sample_transport(RenderCtx& R, TransportNode& tn, uint32_t mi, int sampleI,
         V3 normal = shading_normal(S, m, tn.hit);   // meta->normal
         const float roughness = m.roughness;
         tn.specularity = 1.0f - roughness;
+        tn.typeBounce = true;
         bool neeEnabled = roughness > 0;
         bool useNEE = neeEnabled && rc.unit(DIM_NEE_CHOICE) > 0.5;
         tn.isNEERay = useNEE;
@@ -1528,7 +1543,10 @@ RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf in
     }
     switch (m.type) {
     case RTGPU_MAT_DIFFUSE: { // DiffuseMaterial::bsdf, material/DiffuseMaterial.cpp:140-197
-        if (tn.isPhotonMapRay) return rgb_mul(color, tn.photonLighting);   // :154-166 (mode full)
+        if (tn.isPhotonMapRay) { // :154-166
+            RGBf o = rgb_mul(color, tn.photonLighting);
+            return S.pmMode == RTGPU_PM_CAUSTICS ? rgb_scale_f(o, (float)2) : o;
+        }
         double angle = std::max(0.0f, dot(shading_normal(S, m, tn.hit), tn.transportDirection));
         RGBf value;
         if (tn.isNEERay) {
@@ -1560,6 +1578,7 @@ RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf in
         return incoming;
     case RTGPU_MAT_GLASS: { // GlassMaterial::bsdf, material/GlassMaterial.cpp:135-178
         const TransportNode::GlassMeta& meta = tn.glass[tn.leafSlot];
+        if (std::isnan(meta.reflectionWeight)) return RGBf{};   // :139-144
         V3 normal = tn.hit.normal;
         V3 direction = tn.transportDirection;
         bool isInternalRay = dot(normal, direction) < 0;
@@ -1610,6 +1629,7 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
     int curI = startIdx;
     bool pathDone = false, pathTerminated = false;
     bool hasPassedVariance = false;
+    bool pendingCallback = false;   // curNodeCallback of renderer/Renderer.cpp:22, 40-50
     do {
         TransportNode& cur = path[curI];
         uint32_t mi = hit_material(S, cur.hit);
@@ -1623,6 +1643,21 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
         RandCtx rc{key.seed, key.pixel, (uint32_t)(key.geomI * key.materialAA + sampleJ), (uint32_t)curI};
         SampleOut so;
         sample_transport(R, cur, mi, sampleI, sampleCount, rc, 0, so);
+        if (pendingCallback) {
+            // the callback DiffuseMaterial left at the previous vertex (material/DiffuseMaterial.cpp:106-134): this
+            // vertex turned out specular, so the previous one ends the path with the caustic map's estimate
+            TransportNode& prev = path[curI - 1];
+            if (cur.specularity > 0.8) {
+                prev.pathTerminationChance = 1.0f;
+                prev.isEmissive = true;
+                rtgpu_photon_gather g = gather_photons(S, prev.hit.hitpoint(), -prev.hit.rd);
+                RGBf value{g.energy[0], g.energy[1], g.energy[2]};
+                prev.photonLighting = rgb_div_d(rgb_div_d(value, PI * (g.max_dist * g.max_dist)), PI);
+                prev.isPhotonMapRay = true;
+            }
+            if (prev.isEmissive || prev.pathTerminationChance == 1.0f) break;   // Renderer.cpp:44-47: curI stays, the path ends at prev
+        }
+        pendingCallback = so.causticsCallback;
         pathTerminated = (curI + 1 == maxPathLength) || (!cur.isEmissive && rc.unit(DIM_RR) < cur.pathTerminationChance);
         pathDone = cur.isEmissive || pathTerminated;
         if (!pathDone) {

@@ -60,6 +60,8 @@ constexpr uint32_t ST_GLASS_INTERNAL = 1u << 11;  // ... and its transport direc
 constexpr uint32_t ST_GLASS_STICKY = 1u << 12;    // ... and a visibility query along its other direction is in flight
 constexpr uint32_t ST_DIFFUSE_SHIFT = 13;         // 4 bits: earlier vertices of the path with specularity < 0.8 (photon-map mode)
 constexpr uint32_t ST_DIFFUSE_MASK = 15u << ST_DIFFUSE_SHIFT;
+constexpr uint32_t ST_PREV_DIFFUSE = 1u << 17;    // caustics mode: the previous vertex was a diffuse bounce (it left a callback)
+constexpr uint32_t ST_PREV_ROUGH = 1u << 18;      // caustics mode: the previous vertex was a bounce with specularity < 0.8
 
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
@@ -91,6 +93,12 @@ struct Pool {
     uint32_t* qB;
     uint32_t* qShadow;
     uint32_t* qPhoton;    // paths whose diffuse vertex reads the photon map (scenes with a photon map)
+    // caustics mode: what the last diffuse bounce of a path would be worth as the end of the path --
+    // hit point, incoming direction, throughput x colour, value collected before it
+    float4* cHit;
+    float4* cDir;
+    float4* cThrColor;
+    float4* cBase;
     uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] photon queue size, [3] prefix rays repeated per material sample
 };
 
@@ -451,8 +459,25 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             const RGBf color = surface_color(mat);
             const F3 hitpoint = o + (d * t); // RayHitInfo::getHitpoint, math/RayHitInfo.h:48-51
             const bool lastVertex = (k + 1 == maxLen); // such a path is "terminated" and contributes nothing
+            // caustics mode (PhotonMapMode::caustics): the callback a diffuse bounce leaves behind fires when this
+            // vertex is specular (specularity > 0.8: glass, transparent, glossy with roughness < 0.2) and ends the
+            // path at that bounce with the caustic map's estimate (material/DiffuseMaterial.cpp:104-135,
+            // renderer/Renderer.cpp:40-47); glass behind a rough bounce is black (material/GlassMaterial.cpp:31-38)
+            const bool caustics = RICH && sv.pmMode == RTGPU_PM_CAUSTICS;
+            const uint32_t prevFlags = state & (ST_PREV_DIFFUSE | ST_PREV_ROUGH);
+            state &= ~(ST_PREV_DIFFUSE | ST_PREV_ROUGH);
+            float specularity = 0.0f;
+            if (mat.type == RTGPU_MAT_GLOSSY) specularity = 1.0f - mat.roughness;
+            else if (mat.type == RTGPU_MAT_GLASS || mat.type == RTGPU_MAT_TRANSPARENT) specularity = 1.0f;
 
-            if (mat.type == RTGPU_MAT_EMISSIVE) {
+            if (caustics && (prevFlags & ST_PREV_DIFFUSE) && specularity > 0.8) {
+                done = true;
+                pushPhoton = true;
+            } else if (caustics && mat.type == RTGPU_MAT_GLASS && k != 0 && (prevFlags & ST_PREV_ROUGH)) {
+                done = true;
+                completed = !lastVertex;
+                result = rgb_mul(thr, addE);
+            } else if (mat.type == RTGPU_MAT_EMISSIVE) {
                 // EmissiveMaterial (material/EmissiveMaterial.cpp:5-22)
                 done = true;
                 completed = !lastVertex;
@@ -620,6 +645,8 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             const double angle = fmaxf(0.0f, dot3(normal, dir));
                             const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
                             const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
+                            const RGBf thrBefore = thr, accBefore = acc;
+                            const F3 rayDirIn = d;
                             if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
                             thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
                             o = hitpoint + (dir * 0.0001f);
@@ -627,6 +654,14 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             writeThr = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
                             if (RICH && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity 0
+                            if (caustics) {
+                                state |= ST_PREV_DIFFUSE | ST_PREV_ROUGH;
+                                const RGBf tc = rgb_mul(thrBefore, color), cb = rgb_add(accBefore, rgb_mul(thrBefore, addE));
+                                pool.cHit[p] = f4(hitpoint.x, hitpoint.y, hitpoint.z, 0.0f);
+                                pool.cDir[p] = f4(rayDirIn.x, rayDirIn.y, rayDirIn.z, 0.0f);
+                                pool.cThrColor[p] = f4(tc.r, tc.g, tc.b, 0.0f);
+                                pool.cBase[p] = f4(cb.r, cb.g, cb.b, 0.0f);
+                            }
                             pushExt = true;
                             done = true;
                         }
@@ -673,6 +708,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                             writeAux = true;
                             state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
                             if (RICH && (1.0f - roughness) < 0.8 && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity = 1 - roughness
+                            if (caustics && (1.0f - roughness) < 0.8) state |= ST_PREV_ROUGH;
                             pushExt = true;
                         }
                     }
@@ -697,7 +733,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
     }
     queue_push2<kShadeBlock>(qExt, pool.counters + 0, pushExt, pool.qShadow, pool.counters + 1, pushShadow, p);
     if (RICH) {
-        if (sv.pmMode == RTGPU_PM_FULL) queue_push1<kShadeBlock>(pool.qPhoton, pool.counters + 2, pushPhoton, p);   // uniform branch
+        if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, pool.counters + 2, pushPhoton, p);   // uniform branch
     }
     // Extension rays of vertices before the first variance vertex are identical for every material
     // sample j (the reference traces them once per geometry sample): count the repeats so that
@@ -762,10 +798,20 @@ __global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, P
     const uint32_t q = blockIdx.x * 64u + threadIdx.x;
     if (q >= n) return;
     const uint32_t p = pool.qPhoton[q];
-    const float4 ra = pool.rayA[p], rb = pool.rayB[p], au = pool.aux[p], tq = pool.thr[p], base = pool.result[p];
     uint32_t count;
     float maxDist;
     RGBf value;
+    if (sv.pmMode == RTGPU_PM_CAUSTICS) {
+        // the diffuse bounce before a specular vertex: value / (pi * maxDist^2) / pi, bsdf = colour * that * 2
+        // (material/DiffuseMaterial.cpp:113-128, 154-164)
+        const float4 ch = pool.cHit[p], cd = pool.cDir[p], tc = pool.cThrColor[p], cb = pool.cBase[p];
+        gather_photons(sv, f3(ch.x, ch.y, ch.z), f3(-cd.x, -cd.y, -cd.z), count, maxDist, value);
+        const RGBf photonLighting = rgb_div_d(rgb_div_d(value, RT_PI * (maxDist * maxDist)), RT_PI);
+        const RGBf out = rgb_scale_f(rgb_mul(rgb(tc.x, tc.y, tc.z), photonLighting), (float)2);
+        pool.result[p] = f4(cb.x + out.r, cb.y + out.g, cb.z + out.b, 0.0f);
+        return;
+    }
+    const float4 ra = pool.rayA[p], rb = pool.rayB[p], au = pool.aux[p], tq = pool.thr[p], base = pool.result[p];
     gather_photons(sv, f3(ra.x, ra.y, ra.z), f3(-rb.x, -rb.y, -rb.z), count, maxDist, value);
     const DevMaterial& m = sv.materials[__float_as_uint(au.w)];
     const RGBf photonLighting = rgb_div_d(rgb_div_d(rgb_scale_d(value, m.intensity), (RT_PI * maxDist) * maxDist), RT_PI);
@@ -917,13 +963,15 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
         pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
         pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
-        pool.qPhoton = ws.alloc<uint32_t>(sv.pmMode == RTGPU_PM_FULL ? P : 1);
+        pool.qPhoton = ws.alloc<uint32_t>(sv.pmMode != RTGPU_PM_NONE ? P : 1);
+        const size_t nC = sv.pmMode == RTGPU_PM_CAUSTICS ? P : 1;
+        pool.cHit = ws.alloc<float4>(nC); pool.cDir = ws.alloc<float4>(nC); pool.cThrColor = ws.alloc<float4>(nC); pool.cBase = ws.alloc<float4>(nC);
         pool.counters = ws.alloc<uint32_t>(4);
         if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
-        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode == RTGPU_PM_FULL;
+        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode != RTGPU_PM_NONE;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
             Batch batch;
