@@ -4,11 +4,12 @@
 //
 //   render_glb --scene scene.glb --width 500 --height 500 [--xstart .. --ystart .. --xend .. --yend ..]
 //              [--soupify] [--aageometry 4] [--aamaterial 4] [--seed 0] [--outputtype exr|png|ppm|tile] [--output output]
-//              [--exposure -2.5] [--gamma 2.2]
+//              [--exposure -2.5] [--gamma 2.2] [--pmmode none|caustics|full] [--pmdepth 0]
+//              [--pmrayspointlamp 10000000] [--pmraysarealamp 10000000]
 //
 // Output: "exr" (half floats, io/EXRWriter.cpp) and "png" (exposure + gamma, io/PNG.cpp) through the library's
 // writers, "tile" = the TILE exchange file of io/TileFile.cpp:8-27, "ppm" = the text PPM of io/PPMFile.cpp:4-24.
-// (Photon mapping, tile merging and the preview window stay with the reference's executable.)
+// (Photon map files, tile merging and the preview window stay with the reference's executable.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -52,14 +53,15 @@ void writePpm(const std::vector<float>& pixels, int width, int height, const std
 int main(int argc, char** argv)
 {
     std::map<std::string, std::string> opt = {{"scene", "scene.glb"}, {"width", "500"}, {"height", "500"}, {"xstart", "0"}, {"ystart", "0"},
-                                              {"outputtype", "exr"}, {"output", "output"}, {"exposure", "-2.5"}, {"gamma", "2.2"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"}};
+                                              {"outputtype", "exr"}, {"output", "output"}, {"exposure", "-2.5"}, {"gamma", "2.2"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"},
+                                              {"pmmode", "none"}, {"pmdepth", "0"}, {"pmrayspointlamp", "10000000"}, {"pmraysarealamp", "10000000"}};
     bool soupify = false;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "unexpected argument %s\n", argv[i]); return -1; }
         a = a.substr(2);
         if (a == "soupify") { soupify = true; continue; }
-        if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma\n"); return 0; }
+        if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma --pmmode --pmdepth --pmrayspointlamp --pmraysarealamp\n"); return 0; }
         if (i + 1 >= argc) { std::fprintf(stderr, "option --%s needs a value\n", a.c_str()); return -1; }
         opt[a] = argv[++i];
     }
@@ -78,6 +80,16 @@ int main(int argc, char** argv)
     const std::string type = opt["outputtype"];
     if (type != "exr" && type != "png" && type != "ppm" && type != "tile") { std::fprintf(stderr, "Invalid output type: %s\n", type.c_str()); return -1; }
 
+    // exe/Raytracer.cpp:210-227, 237-241
+    const std::string pm = opt["pmmode"];
+    int pmMode;
+    if (pm == "none") pmMode = RTGPU_PM_NONE;
+    else if (pm == "caustics") pmMode = RTGPU_PM_CAUSTICS;
+    else if (pm == "full") pmMode = RTGPU_PM_FULL;
+    else { std::fprintf(stderr, "Invalid photon mapping mode: %s\n", pm.c_str()); return -1; }
+    const unsigned long long pmPoint = std::strtoull(opt["pmrayspointlamp"].c_str(), nullptr, 10), pmArea = std::strtoull(opt["pmraysarealamp"].c_str(), nullptr, 10);
+    if (pmPoint == 0 || pmArea == 0) { std::fprintf(stderr, "Invalid PM raycount settings!\n"); return -1; }
+
     rtgpu_gltf* file = nullptr;
     try {
         std::printf("Loading scene.\n");
@@ -87,6 +99,11 @@ int main(int argc, char** argv)
         rtgpu::GpuScene scene(*rtgpu_gltf_scene_desc(file));     // DynamicScene::build
         rtgpu_gltf_free(file);
         file = nullptr;
+        if (pmMode != RTGPU_PM_NONE) {   // PhotonMapBuilder::buildPhotonMap + Scene::setPhotonMap, exe/Raytracer.cpp:296-323
+            uint64_t nPhotons = 0;
+            rtgpu::check(rtgpu_scene_build_photon_map(scene.mutableHandle(), pmMode, std::atoi(opt["pmdepth"].c_str()), pmPoint, pmArea, settings.seed, &nPhotons));
+            std::printf("Building photon KD-tree (%llu photons)\n", (unsigned long long)nPhotons);
+        }
         rtgpu::GpuRenderer renderer(scene, camera);
         std::vector<float> pixels((size_t)width * height * 3, 0.0f);
         const rtgpu::Tile tile{xstart, ystart, xend, yend};

@@ -60,6 +60,7 @@ public:
     GpuScene& operator=(const GpuScene&) = delete;
 
     const rtgpu_scene* handle() const { return scene_; }
+    rtgpu_scene* mutableHandle() { return scene_; }   // for rtgpu_scene_build_photon_map / rtgpu_scene_set_photons
 
     // Scene::traceRay (scene/renderable/Scene.cpp:14-17)
     std::optional<rtgpu_hit> traceRay(const float origin[3], const float direction[3]) const

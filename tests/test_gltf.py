@@ -318,6 +318,18 @@ def test_render_glb_program_follows_the_reference_command_line(tmp_path):
         with api.Scene(g.desc) as scene:
             img, _ = api.Renderer().render(scene, g.camera(), st)
     assert np.array_equal(px, img[4:40, 8:56]) and px.mean() > 0.05
+    # --pmmode full: the photon map is built from the same arguments on both sides
+    run = subprocess.run([exe, "--scene", path, "--width", "64", "--height", "48", "--aageometry", "2", "--aamaterial", "2", "--seed", "9",
+                          "--pmmode", "full", "--pmdepth", "1", "--pmrayspointlamp", "20000", "--pmraysarealamp", "20000",
+                          "--outputtype", "tile", "--output", out + "_pm"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    _, _, _, px_pm = tilefile.read_tile_file(out + "_pm.tile")
+    with gltf.load_glb(path, 64 / 48) as g:
+        with api.Scene(g.desc) as scene:
+            n_photons = scene.build_photon_map(abi.PM_FULL, 1, 20000, 20000, seed=9)
+            img_pm, _ = api.Renderer().render(scene, g.camera(), abi.make_settings(64, 48, geometry_aa=2, material_aa=2, seed=9))
+    assert "Building photon KD-tree (%d photons)" % n_photons in run.stdout and n_photons > 1000   # an open scene: most rays leave it
+    assert np.array_equal(px_pm, img_pm)
     b = gltf.GlbBuilder()
     v, n, idx, uv = _quad()
     b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, None, None)]))
