@@ -84,7 +84,8 @@ struct SceneView {
     int32_t hasAdd;             // some material is an add material: paths carry a collected-emission record
     int32_t hasNormalMap;
     // photon map (null / 0 without one): photons in search order (every range [lo, hi) has the median of its
-    // axis at lo + (hi - lo) / 2), xyz of position / surface normal / energy
+    // axis at lo + (hi - lo) / 2), xyz of position / surface normal / energy; kdPos holds two records per photon:
+    // the position, and the cone of the normals of the range rooted there (axis, cull limit)
     const float4* kdPos;
     const float4* kdNormal;
     const float4* kdEnergy;

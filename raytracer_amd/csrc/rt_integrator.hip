@@ -610,7 +610,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     outAuxW = __uint_as_float(mi);
                     writeAux = true;
                     writeThr = true;
-                    pushPhoton = true;
+                    // before any variance vertex all material samples j are the same path and only j = 0 is read
+                    // (resolve_kernel): the others skip the search
+                    pushPhoton = passed || j == 0u;
                 } else if (mat.type == RTGPU_MAT_DIFFUSE) {
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;

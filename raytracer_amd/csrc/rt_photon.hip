@@ -12,9 +12,10 @@
 //   tree   : the reference sorts each slice along the next axis (y, z, x, ...) and takes the element at count / 2.
 //            The same tree is kept here without pointers: photons are permuted so that every range [lo, hi) has
 //            its axis median at lo + (hi - lo) / 2 (std::nth_element, host threads for the upper levels).
-//   gather : one lane per query point, depth-first with a stack of ranges in private memory and a bounded
-//            max-heap of the k best; the k nearest photons that pass the filter are the same set whatever the
-//            tree, distance ties aside.
+//   gather : one lane per query point, depth-first in the reference's order (near side, node, far side) with a stack
+//            of far ranges in private memory and a bounded max-heap of the k best; ranges whose cone of photon
+//            normals cannot pass the query's filter are skipped.  The k nearest photons that pass the filter are
+//            the same set whatever the tree, distance ties aside.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -248,6 +249,51 @@ void kd_order(const std::vector<rtgpu_photon>& ph, uint32_t* idx, size_t lo, siz
     }
 }
 
+// Bounding cone of the surface normals of every range (stored at the range's middle element): axis and the
+// value the gather compares dot(dir, axis) / |dir| with -- below it no normal of the range can pass the filter
+// dir . normal >= 0.  Built bottom-up and conservatively: half angle = the largest of the node's own deviation and
+// each child cone's axis deviation plus its half angle, a little inflated; ranges whose cone reaches 90 degrees
+// are never culled (limit -2).
+struct Cone { double sx, sy, sz; float ax, ay, az; double alpha; };
+Cone kd_cones(const std::vector<rtgpu_photon>& ph, const uint32_t* idx, std::vector<float4>& out, size_t lo, size_t hi, int spawnLevels)
+{
+    const size_t mid = lo + (hi - lo) / 2;
+    const rtgpu_photon& p = ph[idx[mid]];
+    Cone l{}, r{};
+    const bool hasL = mid > lo, hasR = hi > mid + 1;
+    if (spawnLevels > 0 && hi - lo > 100000) {
+        std::thread t([&] { l = kd_cones(ph, idx, out, lo, mid, spawnLevels - 1); });
+        if (hasR) r = kd_cones(ph, idx, out, mid + 1, hi, spawnLevels - 1);
+        t.join();
+    } else {
+        if (hasL) l = kd_cones(ph, idx, out, lo, mid, 0);
+        if (hasR) r = kd_cones(ph, idx, out, mid + 1, hi, 0);
+    }
+    Cone c{};
+    c.sx = p.normal[0] + (hasL ? l.sx : 0.0) + (hasR ? r.sx : 0.0);
+    c.sy = p.normal[1] + (hasL ? l.sy : 0.0) + (hasR ? r.sy : 0.0);
+    c.sz = p.normal[2] + (hasL ? l.sz : 0.0) + (hasR ? r.sz : 0.0);
+    const double len = std::sqrt(c.sx * c.sx + c.sy * c.sy + c.sz * c.sz);
+    const double kPi = 3.14159265358979323;
+    c.alpha = kPi;
+    if (len > 1e-6 && std::isfinite(len)) {
+        const double ax = c.sx / len, ay = c.sy / len, az = c.sz / len;
+        c.ax = (float)ax; c.ay = (float)ay; c.az = (float)az;
+        auto angle = [&](double x, double y, double z) {
+            const double n = std::sqrt(x * x + y * y + z * z);
+            if (!(n > 0) || !std::isfinite(n)) return kPi;   // a degenerate normal: its dot product with anything is 0 or NaN, keep the range
+            return std::acos(std::max(-1.0, std::min(1.0, (x * c.ax + y * c.ay + z * c.az) / n)));
+        };
+        double a = angle(p.normal[0], p.normal[1], p.normal[2]);
+        if (hasL) a = std::max(a, angle(l.ax, l.ay, l.az) + l.alpha);
+        if (hasR) a = std::max(a, angle(r.ax, r.ay, r.az) + r.alpha);
+        c.alpha = std::min(kPi, a + 1e-3);
+    }
+    const float limit = c.alpha < 0.5 * kPi - 1e-3 ? (float)(-std::sin(c.alpha) - 1e-4) : -2.0f;
+    out[2 * mid + 1] = make_float4(c.ax, c.ay, c.az, limit);
+    return c;
+}
+
 struct Dev {
     void* p = nullptr;
     ~Dev() { if (p) (void)hipFree(p); }
@@ -280,21 +326,22 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
         std::vector<uint32_t> idx(n);
         for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
         kd_order(ph, idx.data(), 0, n, 0, 4);
-        std::vector<float4> pos(n), nrm(n), en(n);
+        std::vector<float4> pos(2 * n), nrm(n), en(n);   // pos: position and normal cone of the range rooted at the element
+        kd_cones(ph, idx.data(), pos, 0, n, 4);
         for (size_t i = 0; i < n; ++i) {
             const rtgpu_photon& p = ph[idx[i]];
-            pos[i] = make_float4(p.pos[0], p.pos[1], p.pos[2], 0.0f);
+            pos[2 * i] = make_float4(p.pos[0], p.pos[1], p.pos[2], 0.0f);
             nrm[i] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.0f);
             en[i] = make_float4(p.energy[0], p.energy[1], p.energy[2], 0.0f);
         }
         void *dp = nullptr, *dn = nullptr, *de = nullptr;
-        PH_HIP(hipMalloc(&dp, n * sizeof(float4)));
+        PH_HIP(hipMalloc(&dp, 2 * n * sizeof(float4)));
         v.kdPos = (const float4*)dp;
         PH_HIP(hipMalloc(&dn, n * sizeof(float4)));
         v.kdNormal = (const float4*)dn;
         PH_HIP(hipMalloc(&de, n * sizeof(float4)));
         v.kdEnergy = (const float4*)de;
-        PH_HIP(hipMemcpy(dp, pos.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dp, pos.data(), 2 * n * sizeof(float4), hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(dn, nrm.data(), n * sizeof(float4), hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(de, en.data(), n * sizeof(float4), hipMemcpyHostToDevice));
     }

@@ -18,48 +18,61 @@ __device__ inline void gather_photons(const SceneView& sv, F3 q, F3 dir, uint32_
     uint32_t hi_[kGatherK];
     int found = 0;
     float r2 = 1E9f * 1E9f;   // getElementsNearestTo(hitpoint, 20, 1E9, ...)
-    struct Range { uint32_t lo, hi; float plane2; uint32_t depth; };
-    Range stack[40];
+    // The walk follows KDTreeNode::getElementsNearestTo (photonmapping/KDTree.h:90-164): the child on the query's side
+    // first, then the node's own photon, then the other child if the split plane is within the search radius -- near
+    // photons fill the list first and the radius is small before the far sides are looked at.  A stack entry is the
+    // far range of a node; popping it first tests that node's photon (its near subtree is finished by then).
+    constexpr uint32_t kNoParent = 1u << 30, kRightSide = 1u << 31;
+    struct Entry { uint32_t lo, hi; float plane2, d2; uint32_t dk; };   // d2: squared distance of the node's photon; dk: depth | flags
+    Entry stack[40];
     int sp = 0;
-    if (sv.nPhotons) { stack[0] = Range{0u, sv.nPhotons, 0.0f, 0u}; sp = 1; }
+    if (sv.nPhotons) { stack[0] = Entry{0u, sv.nPhotons, 0.0f, 0.0f, kNoParent}; sp = 1; }
     const float qa[3] = {q.x, q.y, q.z};
-    while (sp > 0) {
-        const Range rg = stack[--sp];
-        if (rg.plane2 > r2) continue;   // distanceToSplitPlane <= searchRadius, photonmapping/KDTree.h:153
-        const uint32_t mid = rg.lo + (rg.hi - rg.lo) / 2u;
-        const float4 p = sv.kdPos[mid];
-        const uint32_t axis = (rg.depth + 1u) % 3u;   // KDTreeBuilder::buildNode: the axis after the parent's, x before the root
-        const float pa = axis == 0u ? p.x : (axis == 1u ? p.y : p.z);
-        const float delta = qa[axis] - pa;
-        const bool right = pa < qa[axis];             // targetContainingChildIdx, KDTree.h:122
-        const uint32_t nlo = right ? mid + 1u : rg.lo, nhi = right ? rg.hi : mid;
-        const uint32_t flo = right ? rg.lo : mid + 1u, fhi = right ? mid : rg.hi;
-        if (fhi > flo && sp < 39) stack[sp++] = Range{flo, fhi, delta * delta, rg.depth + 1u};
-        if (nhi > nlo && sp < 39) stack[sp++] = Range{nlo, nhi, 0.0f, rg.depth + 1u};
-        const F3 diff = f3(p.x, p.y, p.z) - q;
-        const float d2 = dot3(diff, diff);
-        if (d2 < r2) {
-            const float4 n = sv.kdNormal[mid];
-            if (dot3(dir, f3(n.x, n.y, n.z)) >= 0) {
-                if (found < kGatherK) {
-                    int c = found++;
-                    while (c > 0 && hd[(c - 1) / 2] < d2) { hd[c] = hd[(c - 1) / 2]; hi_[c] = hi_[(c - 1) / 2]; c = (c - 1) / 2; }
-                    hd[c] = d2; hi_[c] = mid;
-                    if (found == kGatherK) r2 = hd[0];
-                } else {
-                    int c = 0;   // replace the farthest, sift down
-                    for (;;) {
-                        int l = 2 * c + 1, rr = l + 1, big = -1;
-                        float bigv = d2;
-                        if (l < kGatherK && hd[l] > bigv) { big = l; bigv = hd[l]; }
-                        if (rr < kGatherK && hd[rr] > bigv) { big = rr; }
-                        if (big < 0) break;
-                        hd[c] = hd[big]; hi_[c] = hi_[big]; c = big;
-                    }
-                    hd[c] = d2; hi_[c] = mid;
-                    r2 = hd[0];
-                }
+    const float dirLen = norm3(dir);
+    // a photon at squared distance d2: the filter of DiffuseMaterial.cpp:66-68, then KDTreeNode::insert (KDTree.h:225-245)
+    auto offer = [&](uint32_t node, float d2) {
+        if (!(d2 < r2)) return;
+        const float4 n = sv.kdNormal[node];
+        if (!(dot3(dir, f3(n.x, n.y, n.z)) >= 0)) return;
+        if (found < kGatherK) {
+            int c = found++;
+            while (c > 0 && hd[(c - 1) / 2] < d2) { hd[c] = hd[(c - 1) / 2]; hi_[c] = hi_[(c - 1) / 2]; c = (c - 1) / 2; }
+            hd[c] = d2; hi_[c] = node;
+            if (found == kGatherK) r2 = hd[0];
+        } else {
+            int c = 0;   // replace the farthest, sift down
+            for (;;) {
+                int l = 2 * c + 1, rr = l + 1, big = -1;
+                float bigv = d2;
+                if (l < kGatherK && hd[l] > bigv) { big = l; bigv = hd[l]; }
+                if (rr < kGatherK && hd[rr] > bigv) { big = rr; }
+                if (big < 0) break;
+                hd[c] = hd[big]; hi_[c] = hi_[big]; c = big;
             }
+            hd[c] = d2; hi_[c] = node;
+            r2 = hd[0];
+        }
+    };
+    while (sp > 0) {
+        const Entry e = stack[--sp];
+        if (!(e.dk & kNoParent)) offer((e.dk & kRightSide) ? e.lo - 1u : e.hi, e.d2);   // the node whose far range this is
+        if (e.hi <= e.lo || e.plane2 > r2) continue;   // distanceToSplitPlane <= searchRadius, KDTree.h:153
+        uint32_t lo = e.lo, hi = e.hi, depth = e.dk & 0xFFu;
+        while (hi > lo && sp < 40) {                   // down the query's side, leaving the far ranges behind
+            const uint32_t mid = lo + (hi - lo) / 2u;
+            const float4 p = sv.kdPos[2u * mid], cone = sv.kdPos[2u * mid + 1u];
+            // no normal in this range's cone can have a non-negative dot product with dir: nothing here passes the filter
+            if (dot3(dir, f3(cone.x, cone.y, cone.z)) < cone.w * dirLen) break;
+            const F3 diff = f3(p.x, p.y, p.z) - q;
+            const float d2 = dot3(diff, diff);
+            if (hi - lo == 1u) { offer(mid, d2); break; }   // a leaf: nothing below it
+            const uint32_t axis = (depth + 1u) % 3u;   // KDTreeBuilder::buildNode: the axis after the parent's, x before the root
+            const float pa = axis == 0u ? p.x : (axis == 1u ? p.y : p.z);
+            const float delta = qa[axis] - pa;
+            const bool right = pa < qa[axis];          // targetContainingChildIdx, KDTree.h:122
+            depth += 1u;
+            if (right) { stack[sp++] = Entry{lo, mid, delta * delta, d2, depth}; lo = mid + 1u; }
+            else { stack[sp++] = Entry{mid + 1u, hi, delta * delta, d2, depth | kRightSide}; hi = mid; }
         }
     }
     count = (uint32_t)found;
