@@ -336,3 +336,32 @@ def test_render_glb_program_follows_the_reference_command_line(tmp_path):
     b.write(os.path.join(str(tmp_path), "nocam.glb"))
     run = subprocess.run([exe, "--scene", os.path.join(str(tmp_path), "nocam.glb"), "--width", "8", "--height", "8"], capture_output=True, text=True, timeout=120)
     assert run.returncode != 0 and "No camera in scene." in run.stderr
+
+
+def test_damaged_files_are_refused_not_crashed_on(tmp_path):
+    """Bytes of a valid file overwritten at random (JSON chunk, chunk headers, binary chunk): the loader either
+    still reads a scene or returns an error code; it never reads outside its buffers."""
+    path, _, _ = _full_scene(str(tmp_path))
+    data = bytearray(open(path, "rb").read())
+    json_len = struct.unpack_from("<I", data, 12)[0]
+    rng = np.random.RandomState(7)
+    bad = os.path.join(str(tmp_path), "damaged.glb")
+    outcomes = {"ok": 0, "error": 0}
+    for k in range(400):
+        d = bytearray(data)
+        region = (12, 20 + json_len) if k % 2 == 0 else (0, len(d))
+        for _ in range(rng.randint(1, 6)):
+            pos = rng.randint(region[0], region[1])
+            d[pos] = rng.randint(0, 256) if k % 3 else ord(rng.choice(list('{}[]",:0129-e.')))
+        if k % 7 == 0:
+            d = d[:rng.randint(12, len(d))]
+        open(bad, "wb").write(bytes(d))
+        try:
+            with gltf.load_glb(bad, 1.5, soupify=bool(k % 2)) as g:
+                g.scene_data()
+                if g.camera_count():
+                    g.camera()
+            outcomes["ok"] += 1
+        except (api.RtgpuError, ValueError):
+            outcomes["error"] += 1
+    assert outcomes["error"] > 50 and outcomes["ok"] + outcomes["error"] == 400
