@@ -365,3 +365,22 @@ def test_damaged_files_are_refused_not_crashed_on(tmp_path):
         except (api.RtgpuError, ValueError):
             outcomes["error"] += 1
     assert outcomes["error"] > 50 and outcomes["ok"] + outcomes["error"] == 400
+
+
+def test_loader_under_address_and_undefined_behaviour_sanitizers(tmp_path):
+    """tests/native/fuzz_gltf.cpp: the loader's source built for the host with -fsanitize=address,undefined and run on
+    1500 damaged copies of a valid file; any out-of-bounds access or undefined operation aborts the harness."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if not shutil.which("g++") or not os.path.exists("/opt/rocm/include/hip/hip_runtime.h"):
+        pytest.skip("needs g++ and the HIP headers")
+    exe = os.path.join(str(tmp_path), "fuzz_gltf")
+    build = subprocess.run(["g++", "-std=c++17", "-g", "-O1", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-D__HIP_PLATFORM_AMD__",
+                            "-I/opt/rocm/include", "-I" + os.path.join(root, "raytracer_amd", "csrc"), os.path.join(root, "tests", "native", "fuzz_gltf.cpp"),
+                            "-o", exe, "-lz"], capture_output=True, text=True, timeout=600)
+    assert build.returncode == 0, build.stderr[-2000:]
+    path, _, _ = _full_scene(str(tmp_path))
+    run = subprocess.run([exe, path, os.path.join(str(tmp_path), "scratch.glb"), "1500"], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    assert "ok " in run.stdout and "err " in run.stdout
