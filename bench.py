@@ -194,6 +194,17 @@ def main():
         except Exception:
             traffic = None
 
+    # VALU wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU): each occupies a SIMD's issue port
+    # for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs at 2.4 GHz
+    valu_issue = None
+    ppath = os.path.join(HERE, "profiles", "r01e_pmc_summary.json")
+    if os.path.exists(ppath) and (args.width, args.height, args.subdiv) == (1920, 1080, 8):
+        try:
+            valu = json.load(open(ppath))["per_launch"]["SQ_INSTS_VALU"]["mean"]
+            valu_issue = valu * 4.0 / 1024.0 / (kernel_ms_avg * 1e-3 * 2.4e9)
+        except Exception:
+            valu_issue = None
+
     out = {
         "metric": "Mrays/s (primary+secondary) and ms/frame at fixed spp, 1/2/4/8 MI355X",
         "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -210,7 +221,9 @@ def main():
                      "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
                      # the tree and triangles (scene_hbm_bytes) fit the 256 MiB Infinity Cache, so most of the
                      # algorithmic bytes never reach HBM: the measured HBM rate is reported beside the algorithmic one
-                     "hbm_measured_GBps": (traffic / (kernel_ms_avg * 1e-3) / 1e9) if traffic else None},
+                     "hbm_measured_GBps": (traffic / (kernel_ms_avg * 1e-3) / 1e9) if traffic else None,
+                     # what actually binds this kernel: the share of the VALU issue slots (at 2.4 GHz) its instructions take
+                     "valu_issue_frac": valu_issue},
     }
 
     if not args.no_frame:
