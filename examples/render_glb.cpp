@@ -100,8 +100,7 @@ int main(int argc, char** argv)
         rtgpu_gltf_free(file);
         file = nullptr;
         if (pmMode != RTGPU_PM_NONE) {   // PhotonMapBuilder::buildPhotonMap + Scene::setPhotonMap, exe/Raytracer.cpp:296-323
-            uint64_t nPhotons = 0;
-            rtgpu::check(rtgpu_scene_build_photon_map(scene.mutableHandle(), pmMode, std::atoi(opt["pmdepth"].c_str()), pmPoint, pmArea, settings.seed, &nPhotons));
+            const uint64_t nPhotons = scene.buildPhotonMap((rtgpu_photon_map_mode)pmMode, std::atoi(opt["pmdepth"].c_str()), pmPoint, pmArea, settings.seed);
             std::printf("Building photon KD-tree (%llu photons)\n", (unsigned long long)nPhotons);
         }
         rtgpu::GpuRenderer renderer(scene, camera);

@@ -62,6 +62,15 @@ public:
     const rtgpu_scene* handle() const { return scene_; }
     rtgpu_scene* mutableHandle() { return scene_; }   // for rtgpu_scene_build_photon_map / rtgpu_scene_set_photons
 
+    // PhotonMapBuilder::buildPhotonMap + Scene::setPhotonMap (photonmapping/PhotonMapBuilder.cpp:15-41,
+    // exe/Raytracer.cpp:296-323); returns the number of photons.  Later renders of this scene use the map.
+    uint64_t buildPhotonMap(rtgpu_photon_map_mode mode, int depth, uint64_t raysPerPointLight, uint64_t raysPerAreaLight, uint32_t seed = 0)
+    {
+        uint64_t n = 0;
+        check(rtgpu_scene_build_photon_map(scene_, mode, depth, raysPerPointLight, raysPerAreaLight, seed, &n));
+        return n;
+    }
+
     // Scene::traceRay (scene/renderable/Scene.cpp:14-17)
     std::optional<rtgpu_hit> traceRay(const float origin[3], const float direction[3]) const
     {
