@@ -6,15 +6,18 @@
 //              [--soupify] [--aageometry 4] [--aamaterial 4] [--seed 0] [--outputtype exr|png|ppm|tile] [--output output]
 //              [--exposure -2.5] [--gamma 2.2] [--pmmode none|caustics|full] [--pmdepth 0]
 //              [--pmrayspointlamp 10000000] [--pmraysarealamp 10000000]
+//   render_glb --width W --height H --mergetiles a.tile b.tile ... [--outputtype ..] [--output ..]
 //
 // Output: "exr" (half floats, io/EXRWriter.cpp) and "png" (exposure + gamma, io/PNG.cpp) through the library's
 // writers, "tile" = the TILE exchange file of io/TileFile.cpp:8-27, "ppm" = the text PPM of io/PPMFile.cpp:4-24.
-// (Photon map files, tile merging and the preview window stay with the reference's executable.)
+// --mergetiles pastes TILE files into one frame instead of rendering (exe/Raytracer.cpp:260-277, io/TileFile.cpp:29-70).
+// (Photon map files and the preview window stay with the reference's executable.)
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <fstream>
 #include <map>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -32,6 +35,26 @@ void writeTile(const std::vector<float>& pixels, int width, int height, const rt
     out.write(reinterpret_cast<const char*>(&tile), sizeof(tile));
     for (int y = tile.yStart; y < tile.yEnd; ++y)
         out.write(reinterpret_cast<const char*>(&pixels[3 * ((size_t)y * width + tile.xStart)]), sizeof(float) * 3 * (tile.xEnd - tile.xStart));
+}
+
+// load_from_tile_file, io/TileFile.cpp:29-70
+void loadTile(std::vector<float>& pixels, int width, int height, const std::string& path)
+{
+    std::ifstream in(path, std::ios::in | std::ios::binary);
+    char magic[4] = {0, 0, 0, 0};
+    in.read(magic, sizeof(magic));
+    if (!in || std::string(magic, 4) != "TILE") throw std::runtime_error("Bad file");
+    int res[2];
+    in.read(reinterpret_cast<char*>(res), sizeof(res));
+    if (!in || res[0] != width || res[1] != height) throw std::runtime_error("Resolution mismatch");
+    rtgpu::Tile t;
+    in.read(reinterpret_cast<char*>(&t), sizeof(t));
+    if (!in || t.xStart > t.xEnd || t.yStart > t.yEnd || t.xStart < 0 || t.xEnd < 0 || t.yStart < 0 || t.yEnd < 0 || t.xEnd > width || t.yEnd > height)
+        throw std::runtime_error("Invalid tile geometry specification");
+    for (int y = t.yStart; y < t.yEnd; ++y) {
+        in.read(reinterpret_cast<char*>(&pixels[3 * ((size_t)y * width + t.xStart)]), sizeof(float) * 3 * (t.xEnd - t.xStart));
+        if (!in) throw std::runtime_error("Bad file");
+    }
 }
 
 // write_to_ppm, io/PPMFile.cpp:4-24
@@ -56,11 +79,16 @@ int main(int argc, char** argv)
                                               {"outputtype", "exr"}, {"output", "output"}, {"exposure", "-2.5"}, {"gamma", "2.2"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"},
                                               {"pmmode", "none"}, {"pmdepth", "0"}, {"pmrayspointlamp", "10000000"}, {"pmraysarealamp", "10000000"}};
     bool soupify = false;
+    std::vector<std::string> tileFilesToMerge;
     for (int i = 1; i < argc; ++i) {
         std::string a = argv[i];
         if (a.rfind("--", 0) != 0) { std::fprintf(stderr, "unexpected argument %s\n", argv[i]); return -1; }
         a = a.substr(2);
         if (a == "soupify") { soupify = true; continue; }
+        if (a == "mergetiles") {   // multitoken: every following word up to the next option
+            while (i + 1 < argc && std::strncmp(argv[i + 1], "--", 2) != 0) tileFilesToMerge.push_back(argv[++i]);
+            continue;
+        }
         if (a == "help") { std::printf("options: --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma --pmmode --pmdepth --pmrayspointlamp --pmraysarealamp\n"); return 0; }
         if (i + 1 >= argc) { std::fprintf(stderr, "option --%s needs a value\n", a.c_str()); return -1; }
         opt[a] = argv[++i];
@@ -89,6 +117,26 @@ int main(int argc, char** argv)
     else { std::fprintf(stderr, "Invalid photon mapping mode: %s\n", pm.c_str()); return -1; }
     const unsigned long long pmPoint = std::strtoull(opt["pmrayspointlamp"].c_str(), nullptr, 10), pmArea = std::strtoull(opt["pmraysarealamp"].c_str(), nullptr, 10);
     if (pmPoint == 0 || pmArea == 0) { std::fprintf(stderr, "Invalid PM raycount settings!\n"); return -1; }
+
+    if (!tileFilesToMerge.empty()) {   // exe/Raytracer.cpp:260-277
+        std::printf("Merging tile files...\n");
+        std::vector<float> pixels((size_t)width * height * 3, 0.0f);
+        const std::string outFile = opt["output"] + "." + type;
+        try {
+            for (const std::string& f : tileFilesToMerge) {
+                std::printf("%s\n", f.c_str());
+                loadTile(pixels, width, height, f);
+            }
+            if (type == "exr") rtgpu::check(rtgpu_write_exr(outFile.c_str(), pixels.data(), width, height, 0));
+            else if (type == "png") rtgpu::check(rtgpu_write_png(outFile.c_str(), pixels.data(), width, height, std::atof(opt["exposure"].c_str()), std::atof(opt["gamma"].c_str())));
+            else if (type == "tile") writeTile(pixels, width, height, rtgpu::Tile{0, 0, width, height}, outFile);
+            else writePpm(pixels, width, height, outFile);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "%s\n", e.what());
+            return -1;
+        }
+        return 0;
+    }
 
     rtgpu_gltf* file = nullptr;
     try {

@@ -330,6 +330,21 @@ def test_render_glb_program_follows_the_reference_command_line(tmp_path):
             img_pm, _ = api.Renderer().render(scene, g.camera(), abi.make_settings(64, 48, geometry_aa=2, material_aa=2, seed=9))
     assert "Building photon KD-tree (%d photons)" % n_photons in run.stdout and n_photons > 1000   # an open scene: most rays leave it
     assert np.array_equal(px_pm, img_pm)
+    # two tiles rendered by separate runs and merged (the reference's way of spreading a frame over processes)
+    common = ["--scene", path, "--width", "64", "--height", "48", "--aageometry", "4", "--aamaterial", "4", "--seed", "9", "--outputtype", "tile"]
+    for name, (xs, xe) in (("left", (0, 30)), ("right", (30, 64))):
+        run = subprocess.run([exe] + common + ["--xstart", str(xs), "--xend", str(xe), "--output", out + "_" + name], capture_output=True, text=True, timeout=120)
+        assert run.returncode == 0, run.stderr
+    run = subprocess.run([exe, "--width", "64", "--height", "48", "--mergetiles", out + "_left.tile", out + "_right.tile", "--outputtype", "tile",
+                          "--output", out + "_merged"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0 and "Merging tile files..." in run.stdout, run.stderr
+    _, _, whole, px_merged = tilefile.read_tile_file(out + "_merged.tile")
+    with gltf.load_glb(path, 64 / 48) as g:
+        with api.Scene(g.desc) as scene:
+            full, _ = api.Renderer().render(scene, g.camera(), abi.make_settings(64, 48, geometry_aa=4, material_aa=4, seed=9))
+    assert whole == (0, 0, 64, 48) and np.array_equal(px_merged, full)
+    run = subprocess.run([exe, "--width", "32", "--height", "48", "--mergetiles", out + "_left.tile"], capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "Resolution mismatch" in run.stderr          # io/TileFile.cpp:46-49
     b = gltf.GlbBuilder()
     v, n, idx, uv = _quad()
     b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, None, None)]))
