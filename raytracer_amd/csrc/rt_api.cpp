@@ -122,12 +122,6 @@ int validate(const rtgpu_scene_desc* d)
         const rtgpu_material& m = d->materials[i];
         if (m.type < RTGPU_MAT_DIFFUSE || m.type > RTGPU_MAT_ADD) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown material type");
         if (m.texture > d->n_textures || m.normal_map > d->n_textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "material texture index out of range");
-        if (m.normal_map != 0) {
-            // the tangent frame comes from the texture coordinates (shape/TriangleMesh.cpp:130-139); the reference's
-            // fallback for meshes without them (tangent = b - a, texel (0, 0)) is not carried over
-            for (uint32_t k = 0; k < d->n_meshes; ++k)
-                if (!d->meshes[k].texcoords) return fail(RTGPU_ERR_INVALID_ARGUMENT, "normal maps need texture coordinates on every mesh");
-        }
         const bool inner = m.type == RTGPU_MAT_CONSTMIX || m.type == RTGPU_MAT_FRESNELMIX || m.type == RTGPU_MAT_ADD;
         if (inner && (m.first >= d->n_materials || m.second >= d->n_materials))
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "mix / add material child out of range");
@@ -407,11 +401,15 @@ int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
                 std::memcpy(vn + 3, md.normals + 3 * (size_t)i1, 12);
                 std::memcpy(vn + 6, md.normals + 3 * (size_t)i2, 12);
                 if (anyTriMat) triMat[base + s] = md.tri_material ? md.tri_material[tri] : kInvalid;
-                if (anyUV && md.texcoords) {
+                if (anyUV) {
                     float* uv = vertUV.data() + (base + s) * 6;
-                    std::memcpy(uv, md.texcoords + 2 * (size_t)i0, 8);
-                    std::memcpy(uv + 2, md.texcoords + 2 * (size_t)i1, 8);
-                    std::memcpy(uv + 4, md.texcoords + 2 * (size_t)i2, 8);
+                    if (md.texcoords) {
+                        std::memcpy(uv, md.texcoords + 2 * (size_t)i0, 8);
+                        std::memcpy(uv + 2, md.texcoords + 2 * (size_t)i1, 8);
+                        std::memcpy(uv + 4, md.texcoords + 2 * (size_t)i2, 8);
+                    } else {
+                        uv[0] = NAN;   // a mesh without texture coordinates: texture coordinate (0, 0), tangent b - a (shape/TriangleMesh.cpp:141-144)
+                    }
                 }
             }
         });

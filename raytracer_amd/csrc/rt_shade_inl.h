@@ -254,6 +254,7 @@ __device__ __forceinline__ void hit_texcoord(const SceneView& sv, uint32_t slot,
     u = 0.0f; v = 0.0f;
     if (slot == kInvalid || !sv.vertUV) return;
     const float* t = sv.vertUV + (size_t)slot * 6;
+    if (t[0] != t[0]) return;   // scene creation marks the triangles of meshes without texture coordinates with a NaN
     const float alfa = 1.0f - beta - gamma;
     u = ((alfa * t[0]) + (beta * t[2])) + (gamma * t[4]);
     v = ((alfa * t[1]) + (beta * t[3])) + (gamma * t[5]);
@@ -298,12 +299,15 @@ __device__ __forceinline__ F3 sample_normal_map(const SceneView& sv, uint32_t te
         hit_texcoord(sv, slot, beta, gamma, u, v);
         const float4 r1 = sv.tris[(size_t)slot * 3 + 1], r2 = sv.tris[(size_t)slot * 3 + 2];
         const F3 d0 = f3(-r1.x, -r1.y, -r1.z), d1 = f3(-r2.x, -r2.y, -r2.z);   // b - a, c - a (the records hold a - b, a - c)
-        const float* t = sv.vertUV + (size_t)slot * 6;
-        const float m00 = t[2] - t[0], m01 = t[3] - t[1], m10 = t[4] - t[0], m11 = t[5] - t[1];
-        const float det = (m00 * m11) - (m10 * m01);
-        const float invdet = 1.0f / det;
-        const float i00 = m11 * invdet, i01 = -m01 * invdet;
-        const F3 ot = f3((i00 * d0.x) + (i01 * d1.x), (i00 * d0.y) + (i01 * d1.y), (i00 * d0.z) + (i01 * d1.z));
+        const float* t = sv.vertUV ? sv.vertUV + (size_t)slot * 6 : nullptr;
+        F3 ot = d0;   // without texture coordinates: tangent = b - a, shape/TriangleMesh.cpp:141-144
+        if (t && t[0] == t[0]) {
+            const float m00 = t[2] - t[0], m01 = t[3] - t[1], m10 = t[4] - t[0], m11 = t[5] - t[1];
+            const float det = (m00 * m11) - (m10 * m01);
+            const float invdet = 1.0f / det;
+            const float i00 = m11 * invdet, i01 = -m01 * invdet;
+            ot = f3((i00 * d0.x) + (i01 * d1.x), (i00 * d0.y) + (i01 * d1.y), (i00 * d0.z) + (i01 * d1.z));
+        }
         const double* m = sv.instFwd + (size_t)inst * 12;
         const double x = ot.x, y = ot.y, z = ot.z;
         tangent = f3((float)(((m[0] * x + m[1] * y) + m[2] * z) + m[3] * 0.0), (float)(((m[4] * x + m[5] * y) + m[6] * z) + m[7] * 0.0),

@@ -479,11 +479,13 @@ def sun_scene(lights="sun+point"):
     return sc, cam_m, 0.8
 
 
-def textured_scene(seed=3, normal_maps=False):
+def textured_scene(seed=3, normal_maps=False, plain_mesh=False, drop_texcoords=False):
     """The box of box_scene with an albedo map on the floor and the back wall (texture coordinates beyond
     [0, 1) and negative ones included), a gamma-corrected map on one sphere and an emission map on a small panel.
     normal_maps: a bump pattern perturbs the shading normal of the floor (diffuse, with its albedo map), of the
-    first sphere (rough glossy) and of the right wall (mirror)."""
+    first sphere (rough glossy) and of the right wall (mirror).
+    plain_mesh: a second mesh without texture coordinates (a scaled, rotated sphere instance) wears the floor's
+    material.  drop_texcoords: no mesh has texture coordinates (every lookup reads texel (0, 0), tangents are b - a)."""
     rng = np.random.RandomState(seed)
     sc, cam_m, yfov = box_scene()
     mesh = sc.meshes[0]
@@ -527,6 +529,14 @@ def textured_scene(seed=3, normal_maps=False):
                           np.concatenate([mesh.indices, panel_f + np.uint32(nv)]),
                           np.concatenate([tm, np.full(len(panel_f), base + 2, dtype=np.uint32)]),
                           np.concatenate([uv, panel_uv]))]
+    if plain_mesh:
+        us = uv_sphere(12, 6)
+        sc.meshes.append(MeshData(us.vertices, us.normals, us.indices))
+        m, inv = trs((2.1, 1.9, 1.5), (0.0, 0.38268343, 0.0, 0.92387953), (0.45, 0.3, 0.45))
+        sc.instances.append(InstanceData(1, base, m, inv))
+    if drop_texcoords:
+        for k, me in enumerate(sc.meshes):
+            sc.meshes[k] = MeshData(me.vertices, me.normals, me.indices, me.tri_material)
     return sc, cam_m, yfov
 
 

@@ -424,9 +424,12 @@ def test_normal_map_turns_the_shading_normal_into_the_tangent_frame():
     tex[...] = (255, 128, 128, 255)
     light, I = np.array([60.0, 0.0, -2.0]), 5.0e4
     images = {}
-    for mapped in (False, True):
+    # "plain": no texture coordinates -- texel (0, 0) and tangent = second - first vertex (shape/TriangleMesh.cpp:141-144),
+    # +x for both triangles in this vertex order, so the image is the mapped one
+    plain_idx = np.array([[0, 1, 2], [3, 2, 0]], np.uint32)
+    for mapped in (False, True, "plain"):
         sc = SceneData()
-        sc.meshes = [MeshData(v, nrm, idx, None, uv)]
+        sc.meshes = [MeshData(v, nrm, plain_idx, None, None) if mapped == "plain" else MeshData(v, nrm, idx, None, uv)]
         sc.textures = [(tex, 1.0)]
         sc.materials = [MaterialData(MAT_DIFFUSE, (0.8, 0.6, 0.4), normal_map=0 if mapped else None)]
         sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
@@ -435,7 +438,8 @@ def test_normal_map_turns_the_shading_normal_into_the_tangent_frame():
         images[mapped], _ = oracle.OracleScene(sc).render(cam, abi.make_settings(16, 16, geometry_aa=1, material_aa=256,
                                                                                 jitter_mode=abi.JITTER_CENTER, seed=4))
     n_ts = np.array([2 * (1.0 - 0.5), 2 * (128 / 255 - 0.5), 2 * (128 / 255 - 0.5)])
-    frames = {False: np.array([0.0, 0.0, 1.0]), True: n_ts[0] * np.array([1.0, 0, 0]) + n_ts[1] * np.array([0, 1.0, 0]) + n_ts[2] * np.array([0, 0, 1.0])}
+    bent = n_ts[0] * np.array([1.0, 0, 0]) + n_ts[1] * np.array([0, 1.0, 0]) + n_ts[2] * np.array([0, 0, 1.0])
+    frames = {False: np.array([0.0, 0.0, 1.0]), "plain": bent, True: n_ts[0] * np.array([1.0, 0, 0]) + n_ts[1] * np.array([0, 1.0, 0]) + n_ts[2] * np.array([0, 0, 1.0])}
     for mapped, n in frames.items():
         n = n / np.linalg.norm(n)
         want = np.zeros(3)
@@ -448,3 +452,4 @@ def test_normal_map_turns_the_shading_normal_into_the_tangent_frame():
         want /= 256
         assert np.allclose(images[mapped].reshape(-1, 3).mean(axis=0), want, rtol=0.03), mapped
     assert images[True].mean() > 10 * images[False].mean()
+    assert np.allclose(images["plain"], images[True], rtol=1e-5)
