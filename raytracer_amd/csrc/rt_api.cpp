@@ -225,7 +225,14 @@ int rtgpu_set_device(int device)
     return RTGPU_OK;
 }
 
+static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene);
+
 int rtgpu_scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
+{
+    return rt::guarded([&]() -> int { return scene_create(desc, out_scene); });
+}
+
+static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
 {
     using namespace rt;
     if (!out_scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "out_scene is null");
@@ -717,10 +724,12 @@ int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera, co
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
     if (!d_rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
     RT_HIP(hipSetDevice(scene->device));
-    std::string err;
-    hipError_t e = rt::render_wavefront(*scene, *camera, *settings, d_rgb_out, stats, (hipStream_t)hip_stream, err);
-    if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
-    return RTGPU_OK;
+    return rt::guarded([&]() -> int {
+        std::string err;
+        hipError_t e = rt::render_wavefront(*scene, *camera, *settings, d_rgb_out, stats, (hipStream_t)hip_stream, err);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+        return RTGPU_OK;
+    });
 }
 
 int rtgpu_render(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,

@@ -439,9 +439,11 @@ int rtgpu_scene_build_photon_map(rtgpu_scene* scene, int32_t mode, int32_t depth
     if (depth < 0 || depth > 15) return rt::set_error(RTGPU_ERR_LIMIT, "photon map depth must be 0..15");
     if (mode != RTGPU_PM_NONE && (rays_per_point_light == 0 || rays_per_area_light == 0))
         return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "Invalid PM raycount settings!");   // exe/Raytracer.cpp:237-241
-    if (int rc = rt::trace_photons(*scene, mode, rays_per_point_light, rays_per_area_light, seed)) return rc;
-    if (n_photons) *n_photons = scene->photons.size();
-    return rt::install_photon_map(*scene, mode, depth);
+    return rt::guarded([&]() -> int {
+        if (int rc = rt::trace_photons(*scene, mode, rays_per_point_light, rays_per_area_light, seed)) return rc;
+        if (n_photons) *n_photons = scene->photons.size();
+        return rt::install_photon_map(*scene, mode, depth);
+    });
 }
 
 int rtgpu_scene_get_photons(const rtgpu_scene* scene, rtgpu_photon* out, uint64_t capacity, uint64_t* n)
@@ -460,8 +462,10 @@ int rtgpu_scene_set_photons(rtgpu_scene* scene, const rtgpu_photon* photons, uin
     if (mode < RTGPU_PM_NONE || mode > RTGPU_PM_FULL) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "unknown photon map mode");
     if (depth < 0 || depth > 15) return rt::set_error(RTGPU_ERR_LIMIT, "photon map depth must be 0..15");
     if (n && !photons) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "null photon buffer");
-    scene->photons.assign(photons, photons + n);
-    return rt::install_photon_map(*scene, mode, depth);
+    return rt::guarded([&]() -> int {
+        scene->photons.assign(photons, photons + n);
+        return rt::install_photon_map(*scene, mode, depth);
+    });
 }
 
 int rtgpu_scene_gather_photons(const rtgpu_scene* scene, const float* points, const float* directions, uint64_t n, rtgpu_photon_gather* out)
@@ -469,7 +473,7 @@ int rtgpu_scene_gather_photons(const rtgpu_scene* scene, const float* points, co
     if (!scene) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
     if (n == 0) return RTGPU_OK;
     if (!points || !directions || !out) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "null query/result buffer");
-    return rt::gather_photons_host(*scene, points, directions, n, out);
+    return rt::guarded([&]() -> int { return rt::gather_photons_host(*scene, points, directions, n, out); });
 }
 
 } // extern "C"

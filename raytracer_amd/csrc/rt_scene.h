@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <new>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -20,6 +22,20 @@ namespace rt {
 
 // Stores the calling thread's error message (rtgpu_last_error) and returns `code`.
 int set_error(int code, const std::string& msg);
+
+// Runs the body of a C entry point: no C++ exception crosses the C boundary (host allocations of scene-sized
+// vectors are the ones that can fail).
+template <typename F>
+int guarded(const F& body)
+{
+    try {
+        return body();
+    } catch (const std::bad_alloc&) {
+        return set_error(RTGPU_ERR_OUT_OF_MEMORY, "out of host memory");
+    } catch (const std::exception& e) {
+        return set_error(RTGPU_ERR_INVALID_ARGUMENT, e.what());
+    }
+}
 
 // Fills normal and area of an area light (AreaLight::getNormal / getSurfaceArea, light/AreaLight.cpp:43-53).
 void area_light_derived(DevAreaLight& l);
