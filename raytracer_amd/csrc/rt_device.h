@@ -65,6 +65,7 @@ struct SceneView {
     uint32_t refTop;            // 1: top-level tree, child order and early exit follow the reference exactly (scenes with spheres)
     int32_t refTopRoot;         // refTop: 0 (inner root) or the leaf reference when the whole list is one leaf
     int32_t stealMinIdle;       // idle lanes a wave needs before it runs a work-stealing round
+    uint32_t gatherBudget;      // tree nodes a photon gather may look at in its first attempt
     int32_t stealLeafPct;       // a wave runs a leaf step once this share (of 128) of its busy lanes waits at a leaf
     // shade stage
     const float* vertNormals;   // per leaf slot: 3 vertex normals (9 floats)

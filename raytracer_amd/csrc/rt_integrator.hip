@@ -31,6 +31,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <thread>
@@ -63,6 +64,8 @@ constexpr uint32_t ST_DIFFUSE_MASK = 15u << ST_DIFFUSE_SHIFT;
 constexpr uint32_t ST_PREV_DIFFUSE = 1u << 17;    // caustics mode: the previous vertex was a diffuse bounce (it left a callback)
 constexpr uint32_t ST_PREV_ROUGH = 1u << 18;      // caustics mode: the previous vertex was a bounce with specularity < 0.8
 
+constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
+
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
 // arrays would each cost a memory transaction of their own).
@@ -93,13 +96,14 @@ struct Pool {
     uint32_t* qB;
     uint32_t* qShadow;
     uint32_t* qPhoton;    // paths whose diffuse vertex reads the photon map (scenes with a photon map)
+    uint32_t* qPhotonTail; // those of them whose gather ran out of its first budget
     // caustics mode: what the last diffuse bounce of a path would be worth as the end of the path --
     // hit point, incoming direction, throughput x colour, value collected before it
     float4* cHit;
     float4* cDir;
     float4* cThrColor;
     float4* cBase;
-    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] photon queue size, [3] prefix rays repeated per material sample
+    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] photon queue size, [3] prefix rays repeated per material sample, [4] photon tail queue size
 };
 
 __device__ __forceinline__ float4 f4(float x, float y, float z, float w)
@@ -795,30 +799,64 @@ __global__ __launch_bounds__(64) void trace_stage_kernel(SceneView sv, Pool pool
 // One lane per path whose diffuse vertex reads the photon map: photonLighting = sum of the 20 nearest photons'
 // energies * diffuseIntensity / (pi * maxDist^2) / pi, bsdf = diffuseColor * photonLighting
 // (material/DiffuseMaterial.cpp:62-75, 154-166), added to what the shade stage stored for the path.
-__global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, Pool pool, uint32_t n)
+// The query of a queued path and what its result adds to the path's value.
+__device__ __forceinline__ void gather_path_query(const SceneView& sv, const Pool& pool, uint32_t p, F3& q, F3& dir)
 {
-    const uint32_t q = blockIdx.x * 64u + threadIdx.x;
-    if (q >= n) return;
-    const uint32_t p = pool.qPhoton[q];
-    uint32_t count;
-    float maxDist;
-    RGBf value;
+    const bool caustics = sv.pmMode == RTGPU_PM_CAUSTICS;
+    const float4 a = caustics ? pool.cHit[p] : pool.rayA[p], b = caustics ? pool.cDir[p] : pool.rayB[p];
+    q = f3(a.x, a.y, a.z);
+    dir = f3(-b.x, -b.y, -b.z);
+}
+__device__ __forceinline__ void gather_path_apply(const SceneView& sv, const Pool& pool, uint32_t p, RGBf value, float maxDist)
+{
     if (sv.pmMode == RTGPU_PM_CAUSTICS) {
         // the diffuse bounce before a specular vertex: value / (pi * maxDist^2) / pi, bsdf = colour * that * 2
         // (material/DiffuseMaterial.cpp:113-128, 154-164)
-        const float4 ch = pool.cHit[p], cd = pool.cDir[p], tc = pool.cThrColor[p], cb = pool.cBase[p];
-        gather_photons(sv, f3(ch.x, ch.y, ch.z), f3(-cd.x, -cd.y, -cd.z), count, maxDist, value);
+        const float4 tc = pool.cThrColor[p], cb = pool.cBase[p];
         const RGBf photonLighting = rgb_div_d(rgb_div_d(value, RT_PI * (maxDist * maxDist)), RT_PI);
         const RGBf out = rgb_scale_f(rgb_mul(rgb(tc.x, tc.y, tc.z), photonLighting), (float)2);
         pool.result[p] = f4(cb.x + out.r, cb.y + out.g, cb.z + out.b, 0.0f);
         return;
     }
-    const float4 ra = pool.rayA[p], rb = pool.rayB[p], au = pool.aux[p], tq = pool.thr[p], base = pool.result[p];
-    gather_photons(sv, f3(ra.x, ra.y, ra.z), f3(-rb.x, -rb.y, -rb.z), count, maxDist, value);
+    const float4 au = pool.aux[p], tq = pool.thr[p], base = pool.result[p];
     const DevMaterial& m = sv.materials[__float_as_uint(au.w)];
     const RGBf photonLighting = rgb_div_d(rgb_div_d(rgb_scale_d(value, m.intensity), (RT_PI * maxDist) * maxDist), RT_PI);
     const RGBf out = rgb_mul(rgb(tq.x, tq.y, tq.z), rgb_mul(rgb(au.x, au.y, au.z), photonLighting));
     pool.result[p] = f4(base.x + out.r, base.y + out.g, base.z + out.b, 0.0f);
+}
+
+// First attempt, one lane per queued path; the paths that run out of budget go to the tail queue (counters[4]).
+__global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, Pool pool, uint32_t n)
+{
+    const uint32_t qi = blockIdx.x * 64u + threadIdx.x;
+    const bool has = qi < n;
+    const uint32_t p = pool.qPhoton[has ? qi : 0u];
+    F3 q, dir;
+    gather_path_query(sv, pool, p, q, dir);
+    uint32_t count;
+    float maxDist;
+    RGBf value;
+    const bool finished = has && gather_photons(sv, q, dir, sv.gatherBudget, count, maxDist, value);
+    if (finished) gather_path_apply(sv, pool, p, value, maxDist);
+    queue_push1<64>(pool.qPhotonTail, pool.counters + 4, has && !finished, p);
+}
+
+// The tail queue, one wave per path.  Launched with a fixed grid right behind the first attempt: the number of
+// queued paths is read on the device.
+__global__ __launch_bounds__(64) void photon_gather_tail_kernel(SceneView sv, Pool pool)
+{
+    __shared__ GatherWaveLds lds;
+    const uint32_t n = pool.counters[4];
+    for (uint32_t qi = blockIdx.x; qi < n; qi += gridDim.x) {
+        const uint32_t p = pool.qPhotonTail[qi];
+        F3 q, dir;
+        gather_path_query(sv, pool, p, q, dir);
+        uint32_t count;
+        float maxDist;
+        RGBf value;
+        gather_photons_wave(sv, q, dir, lds, (int)threadIdx.x, count, maxDist, value);
+        if (threadIdx.x == 0) gather_path_apply(sv, pool, p, value, maxDist);
+    }
 }
 
 // ---- resolve ---------------------------------------------------------------------------------------
@@ -966,13 +1004,16 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
         pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
         pool.qPhoton = ws.alloc<uint32_t>(sv.pmMode != RTGPU_PM_NONE ? P : 1);
+        pool.qPhotonTail = ws.alloc<uint32_t>(sv.pmMode != RTGPU_PM_NONE ? P : 1);
         const size_t nC = sv.pmMode == RTGPU_PM_CAUSTICS ? P : 1;
         pool.cHit = ws.alloc<float4>(nC); pool.cDir = ws.alloc<float4>(nC); pool.cThrColor = ws.alloc<float4>(nC); pool.cBase = ws.alloc<float4>(nC);
-        pool.counters = ws.alloc<uint32_t>(4);
+        pool.counters = ws.alloc<uint32_t>(kPoolCounters);
         if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
         const bool single = sv.singleMesh != 0;
+        const bool gatherStats = std::getenv("RTGPU_GATHER_STATS") != nullptr;
+        const uint32_t tailCap = std::getenv("RTGPU_GATHER_TAIL_BLOCKS") ? (uint32_t)std::atoi(std::getenv("RTGPU_GATHER_TAIL_BLOCKS")) : 16384u;
         const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode != RTGPU_PM_NONE;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
@@ -981,7 +1022,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             batch.nPixels = (uint32_t)std::min<uint64_t>(pixelsPerBatch, nPixelsTotal - start);
             const uint32_t nS = batch.nPixels * G;
             const uint32_t nP = nS * M;
-            LN_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), ls));
+            LN_TRY(hipMemsetAsync(pool.counters, 0, kPoolCounters * sizeof(uint32_t), ls));
             if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
             else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
             ln.primary += nS;
@@ -990,7 +1031,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             uint32_t* qOut = pool.qB;
             // at most one glossy re-trace step per vertex on top of the vertex steps
             for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
-                if (step > 0) LN_TRY(hipMemsetAsync(pool.counters, 0, 4 * sizeof(uint32_t), ls));
+                if (step > 0) LN_TRY(hipMemsetAsync(pool.counters, 0, kPoolCounters * sizeof(uint32_t), ls));
                 const dim3 shadeGrid((nActive + kShadeBlock - 1) / kShadeBlock), shadeBlock(kShadeBlock);
                 if (rich) {
                     if (step == 0) hipLaunchKernelGGL((shade_kernel<true, true>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
@@ -1002,7 +1043,16 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                 LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
                 LN_TRY(hipStreamSynchronize(ls));
                 const uint32_t nExt = h[0], nShadow = h[1], nPhoton = h[2], nRepeated = h[3];
-                if (nPhoton) hipLaunchKernelGGL(photon_gather_stage_kernel, dim3((nPhoton + 63) / 64), dim3(64), 0, ls, sv, pool, nPhoton);
+                if (nPhoton) {
+                    hipLaunchKernelGGL(photon_gather_stage_kernel, dim3((nPhoton + 63) / 64), dim3(64), 0, ls, sv, pool, nPhoton);
+                    hipLaunchKernelGGL(photon_gather_tail_kernel, dim3(std::min(nPhoton, tailCap)), dim3(64), 0, ls, sv, pool);
+                    if (gatherStats) {
+                        uint32_t t = 0;
+                        LN_TRY(hipMemcpyAsync(&t, pool.counters + 4, 4, hipMemcpyDeviceToHost, ls));
+                        LN_TRY(hipStreamSynchronize(ls));
+                        std::fprintf(stderr, "gather: %u queued, %u in the tail\n", nPhoton, t);
+                    }
+                }
                 if (nShadow || nExt) {
                     const uint32_t blocks = (nExt + 63) / 64 + (nShadow + 63) / 64;
                     if (single) hipLaunchKernelGGL((trace_stage_kernel<false>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);

@@ -216,18 +216,51 @@ __global__ void fill_empty_kernel(rtgpu_photon* slots, size_t n)
 
 namespace {
 
-__global__ __launch_bounds__(64) void gather_kernel(SceneView sv, const float* __restrict__ points, const float* __restrict__ dirs, uint64_t n,
-                                                   rtgpu_photon_gather* __restrict__ out)
+__device__ __forceinline__ void store_gather(rtgpu_photon_gather* __restrict__ out, uint32_t i, uint32_t count, float maxDist, RGBf sum)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * 64u + threadIdx.x;
-    if (i >= n) return;
-    uint32_t count;
-    float maxDist;
-    RGBf sum;
-    gather_photons(sv, f3(points[3 * i], points[3 * i + 1], points[3 * i + 2]), f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), count, maxDist, sum);
     rtgpu_photon_gather g;
     g.count = count; g.max_dist = maxDist; g.energy[0] = sum.r; g.energy[1] = sum.g; g.energy[2] = sum.b;
     out[i] = g;
+}
+
+// First attempt, one lane per query, with a bounded number of tree nodes; queries that run out are listed in
+// tail[1..], their number in tail[0] (one atomic per wave), and gather_tail_kernel answers each with a whole wave.
+__global__ __launch_bounds__(64) void gather_kernel(SceneView sv, const float* __restrict__ points, const float* __restrict__ dirs, uint32_t n,
+                                                   rtgpu_photon_gather* __restrict__ out, uint32_t* __restrict__ tail)
+{
+    const uint32_t i = blockIdx.x * 64u + threadIdx.x;
+    bool unfinished = false;
+    if (i < n) {
+        uint32_t count;
+        float maxDist;
+        RGBf sum;
+        if (gather_photons(sv, f3(points[3 * i], points[3 * i + 1], points[3 * i + 2]), f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), sv.gatherBudget, count, maxDist, sum))
+            store_gather(out, i, count, maxDist, sum);
+        else
+            unfinished = true;
+    }
+    const unsigned long long m = __ballot(unfinished);
+    if (m == 0ull) return;
+    const int lane = (int)threadIdx.x, leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(tail, (uint32_t)__popcll(m));
+    base = (uint32_t)__shfl((int)base, leader, 64);
+    if (unfinished) tail[1u + base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+}
+
+__global__ __launch_bounds__(64) void gather_tail_kernel(SceneView sv, const float* __restrict__ points, const float* __restrict__ dirs,
+                                                        rtgpu_photon_gather* __restrict__ out, const uint32_t* __restrict__ tail)
+{
+    __shared__ GatherWaveLds lds;
+    const uint32_t n = tail[0];
+    for (uint32_t qi = blockIdx.x; qi < n; qi += gridDim.x) {
+        const uint32_t i = tail[1u + qi];
+        uint32_t count;
+        float maxDist;
+        RGBf sum;
+        gather_photons_wave(sv, f3(points[3 * i], points[3 * i + 1], points[3 * i + 2]), f3(dirs[3 * i], dirs[3 * i + 1], dirs[3 * i + 2]), lds, (int)threadIdx.x, count, maxDist, sum);
+        if (threadIdx.x == 0) store_gather(out, i, count, maxDist, sum);
+    }
 }
 
 // Permutes idx[lo, hi) so that every range has its median along axis (depth + 1) % 3 in the middle.
@@ -411,7 +444,8 @@ int gather_photons_host(const rtgpu_scene& scene, const float* points, const flo
 {
     PH_HIP(hipSetDevice(scene.device));
     const uint64_t cap = std::min<uint64_t>(n, 1ull << 22);
-    Dev dP, dD, dO;
+    Dev dP, dD, dO, dTail;
+    PH_HIP(hipMalloc(&dTail.p, (cap + 1) * sizeof(uint32_t)));
     PH_HIP(hipMalloc(&dP.p, cap * 12));
     PH_HIP(hipMalloc(&dD.p, cap * 12));
     PH_HIP(hipMalloc(&dO.p, cap * sizeof(rtgpu_photon_gather)));
@@ -419,8 +453,12 @@ int gather_photons_host(const rtgpu_scene& scene, const float* points, const flo
         const uint64_t m = std::min(cap, n - b);
         PH_HIP(hipMemcpy(dP.p, points + 3 * b, m * 12, hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
-        hipLaunchKernelGGL(gather_kernel, dim3((unsigned)((m + 63) / 64)), dim3(64), 0, nullptr, scene.view, (const float*)dP.p, (const float*)dD.p, m,
-                           (rtgpu_photon_gather*)dO.p);
+        PH_HIP(hipMemsetAsync(dTail.p, 0, sizeof(uint32_t), nullptr));
+        const unsigned blocks = (unsigned)((m + 63) / 64);
+        hipLaunchKernelGGL(gather_kernel, dim3(blocks), dim3(64), 0, nullptr, scene.view, (const float*)dP.p, (const float*)dD.p, (uint32_t)m,
+                           (rtgpu_photon_gather*)dO.p, (uint32_t*)dTail.p);
+        hipLaunchKernelGGL(gather_tail_kernel, dim3((unsigned)std::min<uint64_t>(m, 16384)), dim3(64), 0, nullptr, scene.view, (const float*)dP.p, (const float*)dD.p,
+                           (rtgpu_photon_gather*)dO.p, (const uint32_t*)dTail.p);
         PH_HIP(hipGetLastError());
         PH_HIP(hipMemcpy(out + b, dO.p, m * sizeof(rtgpu_photon_gather), hipMemcpyDeviceToHost));
     }

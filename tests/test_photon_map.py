@@ -137,21 +137,54 @@ def test_gpu_photons_and_gather_match_the_oracle():
             assert same.mean() > (0.99 if mode == abi.PM_FULL else 0.97)   # caustic photons come off the curved mirror, which magnifies rounding
             same &= np.isclose(got["energy"], ref["energy"][twin], rtol=1e-5, atol=1e-12).all(1) & (got["is_caustic"] == ref["is_caustic"][twin])
             assert same.mean() > (0.985 if mode == abi.PM_FULL else 0.96)    # photons stacked on one spot may pair with a neighbour of another energy
-        # the gather on one and the same photon set
-        S.build_photon_map(abi.PM_FULL, 0, 25000, 25000, seed=7)
+        _check_gather_on_one_photon_set(S, g)
+
+
+def _check_gather_on_one_photon_set(S, g):
+    S.build_photon_map(abi.PM_FULL, 0, 25000, 25000, seed=7)
+    ph = S.photons()
+    g.set_photons(ph, abi.PM_FULL, 0)
+    rng = np.random.RandomState(1)
+    q = (ph["pos"][rng.randint(0, len(ph), 5000)] + rng.randn(5000, 3) * 0.03).astype(np.float32)
+    d = rng.randn(5000, 3).astype(np.float32)
+    a, b = S.gather_photons(q, d), g.gather_photons(q, d)
+    ties = np.array([brute_gather(ph, q[i], d[i])[3] for i in range(0, 5000, 10)])
+    assert np.array_equal(a["count"], b["count"])
+    ok = np.ones(5000, bool)
+    ok[::10] = ~ties
+    assert np.allclose(a["max_dist"][ok], b["max_dist"][ok], rtol=1e-6)
+    close = np.isclose(a["energy"], b["energy"], rtol=1e-5, atol=1e-9).all(1)
+    assert close[ok].mean() > 0.995
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("budget", ["0", "60"])
+def test_gpu_gather_by_whole_waves_matches_the_oracle(budget, monkeypatch):
+    """A query that runs out of its first budget of tree nodes is answered again by a whole wave.  The budget is read
+    when a scene is created: with 0 nodes every query goes that way, with 60 a part of them; results stay the oracle's,
+    for the gather alone and inside a render."""
+    monkeypatch.setenv("RTGPU_GATHER_BUDGET", budget)
+    sc, cam_m, yfov = scenes.box_scene(with_mirror=True)
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        _check_gather_on_one_photon_set(S, g)
         ph = S.photons()
+        # fewer than 20 photons in the map, and none that passes the filter
+        few = ph[:7]
+        g.set_photons(few, abi.PM_FULL, 0)
+        S.set_photons(few, abi.PM_FULL, 0)
+        q = few["pos"][:3] + np.float32(0.01)
+        for d in (few["normal"][:3], -few["normal"][:3]):
+            a, b = S.gather_photons(q, d), g.gather_photons(q, d)
+            assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["max_dist"], b["max_dist"])
+            assert np.allclose(a["energy"], b["energy"], rtol=1e-6)
+        S.set_photons(ph, abi.PM_FULL, 0)
         g.set_photons(ph, abi.PM_FULL, 0)
-        rng = np.random.RandomState(1)
-        q = (ph["pos"][rng.randint(0, len(ph), 5000)] + rng.randn(5000, 3) * 0.03).astype(np.float32)
-        d = rng.randn(5000, 3).astype(np.float32)
-        a, b = S.gather_photons(q, d), g.gather_photons(q, d)
-        ties = np.array([brute_gather(ph, q[i], d[i])[3] for i in range(0, 5000, 10)])
-        assert np.array_equal(a["count"], b["count"])
-        ok = np.ones(5000, bool)
-        ok[::10] = ~ties
-        assert np.allclose(a["max_dist"][ok], b["max_dist"][ok], rtol=1e-6)
-        close = np.isclose(a["energy"], b["energy"], rtol=1e-5, atol=1e-9).all(1)
-        assert close[ok].mean() > 0.995
+        cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, 48 / 36), cam_m)
+        st = abi.make_settings(48, 36, geometry_aa=2, material_aa=4, seed=11)
+        ref, _ = S.render(cam, st)
+        img, _ = api.Renderer().render(g, cam, st)
+    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-3
 
 
 @pytest.mark.gpu
