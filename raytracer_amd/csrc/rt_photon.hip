@@ -14,8 +14,9 @@
 //            its axis median at lo + (hi - lo) / 2 (std::nth_element, host threads for the upper levels).
 //   gather : one lane per query point, depth-first in the reference's order (near side, node, far side) with a stack
 //            of far ranges in private memory and a bounded max-heap of the k best; ranges whose cone of photon
-//            normals cannot pass the query's filter are skipped.  The k nearest photons that pass the filter are
-//            the same set whatever the tree, distance ties aside.
+//            normals cannot pass the query's filter are skipped.  A query that needs more than a budget of nodes is
+//            answered again by a whole wave (gather_photons_wave).  The k nearest photons that pass the filter are
+//            the same set whatever the tree and the order of the search, distance ties aside.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
