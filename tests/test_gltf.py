@@ -353,6 +353,50 @@ def test_render_glb_program_follows_the_reference_command_line(tmp_path):
     assert run.returncode != 0 and "No camera in scene." in run.stderr
 
 
+@pytest.mark.gpu
+def test_render_glb_program_paths_and_photon_map_files(tmp_path):
+    """The command line of the reference's render_sequence.py: --workdir with "#WORKDIR#" in the scene path
+    (utility/PathResolver.cpp), an output path that already has an extension (kept, exe/Raytracer.cpp:152-155), output
+    directories created (:345), --savepm / --loadpm / --pmfile (:193-206, 296-322): a render from a saved map equals the
+    render that built it."""
+    import subprocess
+    from raytracer_amd import tilefile
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "render_glb")
+    if not os.path.exists(exe):
+        pytest.fail("examples/render_glb is missing: build it with `make -C examples`")
+    work = os.path.join(str(tmp_path), "frames")
+    os.makedirs(work)
+    os.rename(_render_scene(str(tmp_path)), os.path.join(work, "165.glb"))
+    pmfile = os.path.join(str(tmp_path), "photonmap")
+    common = [exe, "--workdir", work, "--scene", "#WORKDIR#/165.glb", "--width", "48", "--height", "36", "--aageometry", "2", "--aamaterial", "2",
+              "--seed", "3", "--outputtype", "tile", "--pmmode", "full", "--pmfile", pmfile]
+    run = subprocess.run(common + ["--output", "out/built.tile", "--pmrayspointlamp", "20000", "--pmraysarealamp", "2E4", "--savepm"],
+                         capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    assert "Building photon map..." in run.stdout and "Saving photon map..." in run.stdout and "Rendering..." in run.stdout
+    built = os.path.join(work, "out", "built.tile")            # relative to the work directory, directory created, extension kept
+    assert "Writing output to " + built in run.stdout and os.path.isfile(built)
+    run = subprocess.run(common + ["--output", os.path.join(str(tmp_path), "loaded"), "--loadpm"], capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stderr
+    n_photons = (os.path.getsize(pmfile) - 16) // 40
+    assert "Loaded %d photons" % n_photons in run.stdout and n_photons > 1000
+    a, b = tilefile.read_tile_file(built)[3], tilefile.read_tile_file(os.path.join(str(tmp_path), "loaded.tile"))[3]
+    assert np.array_equal(a, b) and a.mean() > 0.01
+    # the reference's error exits
+    for args, message in ((["--workdir", os.path.join(work, "nowhere")], "The specified work directory does not exist or is not a folder."),
+                          (["--workdir", work, "--scene", "166.glb"], "The specified scene file does not exist or is not a file."),
+                          (["--workdir", work, "--scene", "165.glb", "--loadpm", "--pmfile", pmfile + "x"], "The specified photon map file does not exist or is not a file."),
+                          (["--workdir", work, "--scene", "165.glb", "--pmmode", "some"], "Invalid photonmapping mode!"),
+                          (["--workdir", work, "--scene", "165.glb", "--aamaterial", "0"], "Invalid AA settings!"),
+                          (["--workdir", work, "--scene", "165.glb", "--pmraysarealamp", "0"], "Invalid PM raycount settings!"),
+                          (["--workdir", work, "--scene", "165.glb", "--samples", "4"], "unrecognised option")):
+        run = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
+        assert run.returncode != 0 and message in run.stderr, (args, run.stderr)
+    open(pmfile + "_bad", "wb").write(b"RTGPUPM1" + struct.pack("<Q", 1 << 40))
+    run = subprocess.run(common[:-1] + [pmfile + "_bad", "--loadpm"], capture_output=True, text=True, timeout=120)
+    assert run.returncode != 0 and "truncated" in run.stderr
+
+
 def test_damaged_files_are_refused_not_crashed_on(tmp_path):
     """Bytes of a valid file overwritten at random (JSON chunk, chunk headers, binary chunk): the loader either
     still reads a scene or returns an error code; it never reads outside its buffers."""
