@@ -304,13 +304,19 @@ std::vector<uint8_t> base64_decode(const char* s, size_t n)
 
 uint32_t be32(const uint8_t* p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
 
-// 8- or 16-bit, non-interlaced PNG -> RGBA8 (the reference's loader asks stb_image for 4 components, io/GLTF.cpp:307-315)
+// PNG -> RGBA8, what the reference's loader gets from stb_image when it asks for 4 components (tinygltf's
+// LoadImageData, io/lib/tiny_gltf.h:1677-1771; loadImage, io/GLTF.cpp:292-316).  stb_image's conventions, from its
+// source text (io/lib/stb_image.h: stbi__depth_scale_table, stbi__compute_transparency, stbi__expand_png_palette):
+// grey samples of 1 / 2 / 4 bits are scaled by 0xff / 0x55 / 0x11, palette indices are not; a tRNS chunk of a grey or
+// RGB image is a colour key (alpha 0 where the pixel equals it, 255 elsewhere), of a palette image one alpha per entry;
+// both interlace methods are read.  A 16-bit image reaches loadImage with 8 bytes per pixel and is refused there.
 void decode_png(const uint8_t* data, size_t n, std::vector<uint8_t>& rgba, uint32_t& width, uint32_t& height)
 {
     static const uint8_t sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
     if (n < 8 || std::memcmp(data, sig, 8)) throw std::runtime_error("glTF image: not a PNG");
     size_t pos = 8;
     int depth = 0, ctype = 0, interlace = 0;
+    bool hasTrns = false;
     std::vector<uint8_t> idat, palette, trns;
     width = height = 0;
     while (pos + 12 <= n) {
@@ -322,14 +328,14 @@ void decode_png(const uint8_t* data, size_t n, std::vector<uint8_t>& rgba, uint3
             width = be32(body); height = be32(body + 4);
             depth = body[8]; ctype = body[9]; interlace = body[12];
         } else if (!std::memcmp(type, "PLTE", 4)) palette.assign(body, body + len);
-        else if (!std::memcmp(type, "tRNS", 4)) trns.assign(body, body + len);
+        else if (!std::memcmp(type, "tRNS", 4)) { trns.assign(body, body + len); hasTrns = true; }
         else if (!std::memcmp(type, "IDAT", 4)) idat.insert(idat.end(), body, body + len);
         else if (!std::memcmp(type, "IEND", 4)) break;
         pos += 12 + (size_t)len;
     }
     if (width == 0 || height == 0 || (uint64_t)width * height > (1ull << 28)) throw std::runtime_error("glTF image: bad PNG size");
-    if (interlace != 0) throw Unsupported("glTF image: interlaced PNG");
-    if (depth != 8 && depth != 16) throw Unsupported("glTF image: PNG bit depth other than 8 or 16");
+    if (interlace > 1) throw std::runtime_error("glTF image: bad PNG interlace method");
+    if (depth != 1 && depth != 2 && depth != 4 && depth != 8 && depth != 16) throw std::runtime_error("glTF image: PNG bit depth must be 1, 2, 4, 8 or 16");
     int channels;
     switch (ctype) {
     case 0: channels = 1; break;
@@ -339,52 +345,97 @@ void decode_png(const uint8_t* data, size_t n, std::vector<uint8_t>& rgba, uint3
     case 6: channels = 4; break;
     default: throw std::runtime_error("glTF image: bad PNG colour type");
     }
-    if (ctype == 3 && depth != 8) throw Unsupported("glTF image: palette PNG with bit depth other than 8");
-    const size_t bpp = (size_t)channels * (depth / 8), stride = bpp * width;
-    std::vector<uint8_t> raw((stride + 1) * height);
+    if ((ctype == 3 && depth == 16) || (depth < 8 && ctype != 0 && ctype != 3)) throw std::runtime_error("glTF image: bad PNG colour type");
+    if (depth == 16) throw std::runtime_error("Can't load image data");   // io/GLTF.cpp:311-313: image.size() != width * height * component
+    if (ctype == 3 && (palette.empty() || palette.size() % 3 != 0 || palette.size() > 768)) throw std::runtime_error("glTF image: bad PNG palette");
+    static const uint8_t scaleOf[9] = {0, 0xff, 0x55, 0, 0x11, 0, 0, 0, 0x01};
+    const uint8_t scale = ctype == 0 ? scaleOf[depth] : 1;
+    uint8_t key[3] = {0, 0, 0};
+    bool keyed = false;
+    if (hasTrns) {
+        if (ctype == 3) {
+            if (trns.size() > palette.size() / 3) throw std::runtime_error("glTF image: bad PNG tRNS length");
+        } else {
+            if (ctype == 4 || ctype == 6) throw std::runtime_error("glTF image: PNG tRNS with alpha");
+            if (trns.size() != (size_t)channels * 2) throw std::runtime_error("glTF image: bad PNG tRNS length");
+            for (int k = 0; k < channels; ++k) key[k] = (uint8_t)(trns[2 * k + 1] * scale);
+            keyed = true;
+        }
+    }
+    const size_t bitsPerPixel = (size_t)channels * depth;
+    const size_t bpp = bitsPerPixel >= 8 ? bitsPerPixel / 8 : 1;   // distance of the filters' "left" byte
+    // the reduced images of the file: one, or the seven passes of Adam7
+    struct Pass { uint32_t x0, y0, dx, dy; };
+    static const Pass whole = {0, 0, 1, 1};
+    static const Pass adam7[7] = {{0, 0, 8, 8}, {4, 0, 8, 8}, {0, 4, 4, 8}, {2, 0, 4, 4}, {0, 2, 2, 4}, {1, 0, 2, 2}, {0, 1, 1, 2}};
+    const Pass* passes = interlace ? adam7 : &whole;
+    const int nPasses = interlace ? 7 : 1;
+    size_t rawSize = 0;
+    for (int p = 0; p < nPasses; ++p) {
+        const uint32_t pw = width > passes[p].x0 ? (width - passes[p].x0 + passes[p].dx - 1) / passes[p].dx : 0;
+        const uint32_t ph = height > passes[p].y0 ? (height - passes[p].y0 + passes[p].dy - 1) / passes[p].dy : 0;
+        if (pw && ph) rawSize += (((size_t)pw * bitsPerPixel + 7) / 8 + 1) * ph;
+    }
+    std::vector<uint8_t> raw(rawSize);
     uLongf rawLen = (uLongf)raw.size();
     if (uncompress(raw.data(), &rawLen, idat.data(), (uLong)idat.size()) != Z_OK || rawLen != raw.size())
         throw std::runtime_error("glTF image: PNG data does not inflate");
-    std::vector<uint8_t> prev(stride, 0), cur(stride);
-    rgba.resize((size_t)width * height * 4);
-    for (uint32_t y = 0; y < height; ++y) {
-        const uint8_t* row = raw.data() + (stride + 1) * y;
-        const int filter = row[0];
-        for (size_t x = 0; x < stride; ++x) {
-            const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
-            int pred = 0;
-            switch (filter) {
-            case 0: pred = 0; break;
-            case 1: pred = a; break;
-            case 2: pred = b; break;
-            case 3: pred = (a + b) / 2; break;
-            case 4: {
-                const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
-                pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-                break;
+    rgba.assign((size_t)width * height * 4, 0);
+    const uint8_t* row = raw.data();
+    for (int p = 0; p < nPasses; ++p) {
+        const Pass& P = passes[p];
+        const uint32_t pw = width > P.x0 ? (width - P.x0 + P.dx - 1) / P.dx : 0;
+        const uint32_t ph = height > P.y0 ? (height - P.y0 + P.dy - 1) / P.dy : 0;
+        if (!pw || !ph) continue;
+        const size_t stride = ((size_t)pw * bitsPerPixel + 7) / 8;
+        std::vector<uint8_t> prev(stride, 0), cur(stride);
+        for (uint32_t y = 0; y < ph; ++y, row += stride + 1) {
+            const int filter = row[0];
+            for (size_t x = 0; x < stride; ++x) {
+                const int a = x >= bpp ? cur[x - bpp] : 0, b = prev[x], c = x >= bpp ? prev[x - bpp] : 0;
+                int pred = 0;
+                switch (filter) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) / 2; break;
+                case 4: {
+                    const int q = a + b - c, pa = std::abs(q - a), pb = std::abs(q - b), pc = std::abs(q - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: throw std::runtime_error("glTF image: bad PNG filter");
+                }
+                cur[x] = (uint8_t)(row[1 + x] + pred);
             }
-            default: throw std::runtime_error("glTF image: bad PNG filter");
+            uint8_t* outRow = rgba.data() + (size_t)(P.y0 + y * P.dy) * width * 4;
+            for (uint32_t x = 0; x < pw; ++x) {
+                uint8_t smp[4] = {0, 0, 0, 0};
+                if (depth == 8) {
+                    for (int k = 0; k < channels; ++k) smp[k] = cur[(size_t)x * channels + k];
+                } else {   // 1, 2 or 4 bits, one channel, most significant bits first
+                    const size_t bit = (size_t)x * depth;
+                    smp[0] = (uint8_t)((cur[bit / 8] >> (8 - depth - (bit % 8))) & ((1u << depth) - 1u));
+                }
+                uint8_t r, g, b, a = 255;
+                if (ctype == 0) {
+                    r = g = b = (uint8_t)(smp[0] * scale);
+                    if (keyed && r == key[0]) a = 0;
+                } else if (ctype == 2) {
+                    r = smp[0]; g = smp[1]; b = smp[2];
+                    if (keyed && r == key[0] && g == key[1] && b == key[2]) a = 0;
+                } else if (ctype == 3) {
+                    const size_t idx = smp[0];
+                    if (idx * 3 + 2 >= palette.size()) throw std::runtime_error("glTF image: PNG palette index out of range");
+                    r = palette[idx * 3]; g = palette[idx * 3 + 1]; b = palette[idx * 3 + 2];
+                    if (idx < trns.size()) a = trns[idx];
+                } else if (ctype == 4) { r = g = b = smp[0]; a = smp[1]; }
+                else { r = smp[0]; g = smp[1]; b = smp[2]; a = smp[3]; }
+                uint8_t* out = outRow + (size_t)(P.x0 + x * P.dx) * 4;
+                out[0] = r; out[1] = g; out[2] = b; out[3] = a;
             }
-            cur[x] = (uint8_t)(row[1 + x] + pred);
+            prev.swap(cur);
         }
-        uint8_t* out = rgba.data() + (size_t)y * width * 4;
-        const size_t step = depth / 8; // a 16-bit sample keeps its high byte
-        for (uint32_t x = 0; x < width; ++x) {
-            const uint8_t* px = cur.data() + x * bpp;
-            uint8_t r, g, b, a = 255;
-            if (ctype == 0) { r = g = b = px[0]; }
-            else if (ctype == 2) { r = px[0]; g = px[step]; b = px[2 * step]; }
-            else if (ctype == 3) {
-                const size_t idx = px[0];
-                if (idx * 3 + 2 >= palette.size()) throw std::runtime_error("glTF image: PNG palette index out of range");
-                r = palette[idx * 3]; g = palette[idx * 3 + 1]; b = palette[idx * 3 + 2];
-                if (idx < trns.size()) a = trns[idx];
-            }
-            else if (ctype == 4) { r = g = b = px[0]; a = px[step]; }
-            else { r = px[0]; g = px[step]; b = px[2 * step]; a = px[3 * step]; }
-            out[4 * x] = r; out[4 * x + 1] = g; out[4 * x + 2] = b; out[4 * x + 3] = a;
-        }
-        prev.swap(cur);
     }
 }
 

@@ -239,6 +239,138 @@ def test_png_round_trip_with_filters(tmp_path):
     assert np.array_equal(got, px) and gamma == 2.2
 
 
+def _write_png(samples, depth, ctype, interlace=False, palette=None, trns=None, filters=(0, 1, 2, 3, 4)):
+    """A PNG file of `samples` (height, width, channels) of `depth` bits each, by the PNG specification: rows packed
+    most significant bit first, every row filter type in turn, optionally the seven Adam7 passes."""
+    import zlib
+    h, w, ch = samples.shape
+    bits = ch * depth
+    bpp = max(1, bits // 8)
+
+    def pack_rows(img):
+        rows = []
+        for y in range(img.shape[0]):
+            if depth == 8:
+                rows.append(img[y].astype(np.uint8).reshape(-1))
+            elif depth == 16:
+                rows.append(img[y].astype(">u2").reshape(-1).view(np.uint8))
+            else:
+                v = img[y].reshape(-1)
+                bitsv = ((v[:, None] >> np.arange(depth - 1, -1, -1)) & 1).astype(np.uint8).reshape(-1)
+                rows.append(np.packbits(bitsv))
+        return rows
+
+    def filtered(rows, first_filter):
+        out = []
+        prev = np.zeros(len(rows[0]), np.int32) if rows else None
+        for y, r in enumerate(rows):
+            cur = r.astype(np.int32)
+            f = filters[(first_filter + y) % len(filters)]
+            left = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            upleft = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]]) if len(cur) > bpp else np.zeros_like(cur)
+            if f == 0: pred = np.zeros_like(cur)
+            elif f == 1: pred = left
+            elif f == 2: pred = prev
+            elif f == 3: pred = (left + prev) // 2
+            else:
+                q = left + prev - upleft
+                pa, pb, pc = np.abs(q - left), np.abs(q - prev), np.abs(q - upleft)
+                pred = np.where((pa <= pb) & (pa <= pc), left, np.where(pb <= pc, prev, upleft))
+            out.append(bytes([f]) + ((cur - pred) % 256).astype(np.uint8).tobytes())
+            prev = cur
+        return b"".join(out)
+
+    if interlace:
+        raw = b""
+        for k, (x0, y0, dx, dy) in enumerate(((0, 0, 8, 8), (4, 0, 8, 8), (0, 4, 4, 8), (2, 0, 4, 4), (0, 2, 2, 4), (1, 0, 2, 2), (0, 1, 1, 2))):
+            sub = samples[y0::dy, x0::dx]
+            if sub.shape[0] and sub.shape[1]:
+                raw += filtered(pack_rows(sub), k)
+    else:
+        raw = filtered(pack_rows(samples), 0)
+
+    def chunk(tag, body):
+        return struct.pack(">I", len(body)) + tag + body + struct.pack(">I", zlib.crc32(tag + body) & 0xFFFFFFFF)
+    comp = zlib.compress(raw)
+    out = b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, depth, ctype, 0, 0, 1 if interlace else 0))
+    if palette is not None:
+        out += chunk(b"PLTE", np.asarray(palette, np.uint8).tobytes())
+    if trns is not None:
+        out += chunk(b"tRNS", bytes(trns))
+    cut = len(comp) // 3
+    return out + chunk(b"IDAT", comp[:cut]) + chunk(b"IDAT", comp[cut:]) + chunk(b"IEND", b"")
+
+
+def _texture_of(png, tmp_path, name="img.glb"):
+    b = gltf.GlbBuilder()
+    b.doc["images"].append({"bufferView": b._view(png), "mimeType": "image/png"})
+    b.doc["textures"].append({"source": 0})
+    v, n, idx, uv = _quad()
+    mat = b.add_material(pbrMetallicRoughness={"baseColorTexture": {"index": 0}})
+    b.add_node(mesh=b.add_primitive_mesh([(v, n, idx, uv, mat)]))
+    path = os.path.join(str(tmp_path), name)
+    b.write(path)
+    with gltf.load_glb(path) as g:
+        (got, _), = g.scene_data().textures
+    return got
+
+
+@pytest.mark.parametrize("interlace", [False, True])
+def test_png_colour_types_bit_depths_and_interlacing(tmp_path, interlace):
+    """Every colour type and bit depth a PNG can have, plain and Adam7, written from known sample values by the PNG
+    specification; expected RGBA by stb_image's conventions, which the reference's loader inherits (read from
+    raytracer/src/lib/io/lib/stb_image.h: stbi__depth_scale_table -- grey of 1 / 2 / 4 bits times 0xff / 0x55 / 0x11,
+    palette indices unscaled; stbi__compute_transparency -- a tRNS colour key gives alpha 0 / 255; per-entry alpha for
+    palettes).  The reference's decoder could not be run here: parity unpinned, the test pins these rules.
+    Sizes 1..9 pixels a side cover Adam7 passes that are empty."""
+    rng = np.random.RandomState(5)
+    for (w, h) in ((9, 7), (1, 1), (3, 2), (8, 8), (5, 9)):
+        for depth in (1, 2, 4, 8):
+            top = (1 << depth) - 1
+            scale = {1: 0xFF, 2: 0x55, 4: 0x11, 8: 1}[depth]
+            # grey, with and without a colour key
+            smp = rng.randint(0, top + 1, size=(h, w, 1))
+            for key in (None, int(smp[0, 0, 0])):
+                got = _texture_of(_write_png(smp, depth, 0, interlace, trns=None if key is None else struct.pack(">H", key)), tmp_path)
+                grey = (smp[..., 0] * scale).astype(np.uint8)
+                alpha = np.full((h, w), 255, np.uint8) if key is None else np.where(smp[..., 0] == key, 0, 255).astype(np.uint8)
+                assert np.array_equal(got, np.stack([grey, grey, grey, alpha], axis=-1)), (w, h, depth, key)
+            # palette, with per-entry alpha for the first entries
+            pal = rng.randint(0, 256, size=(top + 1, 3)).astype(np.uint8)
+            tr = rng.randint(0, 256, size=(top + 1) // 2 + 1).astype(np.uint8)
+            idx = rng.randint(0, top + 1, size=(h, w, 1))
+            got = _texture_of(_write_png(idx, depth, 3, interlace, palette=pal, trns=tr.tobytes()), tmp_path)
+            alpha = np.where(idx[..., 0] < len(tr), tr[np.minimum(idx[..., 0], len(tr) - 1)], 255).astype(np.uint8)
+            assert np.array_equal(got, np.concatenate([pal[idx[..., 0]], alpha[..., None]], axis=-1)), (w, h, depth, "palette")
+        # 8-bit RGB (with a colour key), grey + alpha, RGBA
+        rgb = rng.randint(0, 256, size=(h, w, 3))
+        got = _texture_of(_write_png(rgb, 8, 2, interlace, trns=struct.pack(">HHH", *[int(c) for c in rgb[-1, -1]])), tmp_path)
+        alpha = np.where((rgb == rgb[-1, -1]).all(-1), 0, 255)
+        assert np.array_equal(got, np.concatenate([rgb, alpha[..., None]], axis=-1).astype(np.uint8))
+        ga = rng.randint(0, 256, size=(h, w, 2))
+        got = _texture_of(_write_png(ga, 8, 4, interlace), tmp_path)
+        assert np.array_equal(got, np.stack([ga[..., 0]] * 3 + [ga[..., 1]], axis=-1).astype(np.uint8))
+        rgba = rng.randint(0, 256, size=(h, w, 4))
+        assert np.array_equal(_texture_of(_write_png(rgba, 8, 6, interlace), tmp_path), rgba.astype(np.uint8))
+
+
+def test_png_files_the_reference_refuses(tmp_path):
+    """16-bit images reach loadImage with 8 bytes per pixel and fail its size check ("Can't load image data",
+    io/GLTF.cpp:311-313); malformed headers fail in the decoder (stb_image: "Corrupt PNG")."""
+    rng = np.random.RandomState(2)
+    for ctype, ch in ((0, 1), (2, 3), (4, 2), (6, 4)):
+        with pytest.raises(api.RtgpuError, match="Can't load image data"):
+            _texture_of(_write_png(rng.randint(0, 65536, size=(3, 4, ch)), 16, ctype), tmp_path)
+    bad = [(_write_png(rng.randint(0, 4, size=(3, 4, 3)), 2, 2), "colour type"),                                   # RGB needs 8 or 16 bits
+           (_write_png(rng.randint(0, 256, size=(3, 4, 4)), 8, 6, trns=b"\x00\x01"), "tRNS"),                       # tRNS beside an alpha channel
+           (_write_png(rng.randint(0, 256, size=(3, 4, 3)), 8, 2, trns=b"\x00\x01"), "tRNS"),                       # wrong key length
+           (_write_png(rng.randint(0, 4, size=(3, 4, 1)), 2, 3), "palette"),                                       # no PLTE
+           (_write_png(rng.randint(0, 4, size=(3, 4, 1)), 2, 3, palette=np.zeros((2, 3), np.uint8), trns=b"\x01\x02\x03"), "tRNS")]
+    for png, what in bad:
+        with pytest.raises(api.RtgpuError, match=what):
+            _texture_of(png, tmp_path)
+
+
 def _render_scene(tmp_path):
     """A small room exported to .glb: instanced spheres under a scaled parent, textured floor, lights from extras."""
     b = gltf.GlbBuilder()
