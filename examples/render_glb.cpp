@@ -210,6 +210,7 @@ int main(int argc, char** argv)
             }
         } else {
             std::printf("Loading scene.\n");
+            rtgpu_gltf_set_workdir(workDir.c_str());   // PathResolver::get().setWorkDir(workDir), exe/Raytracer.cpp:112
             rtgpu::check(rtgpu_gltf_load(sceneFile.string().c_str(), static_cast<float>(width) / height, soupify ? 1 : 0, &file));
             rtgpu_camera camera;
             rtgpu::check(rtgpu_gltf_camera(file, &camera));          // Renderer::findCamera: "No camera in scene."

@@ -147,13 +147,20 @@ typedef struct rtgpu_scene_desc {
     uint32_t n_materials;
     uint32_t n_point_lights;
     uint32_t n_area_lights;
-    int32_t has_environment; /* ColorEnvironment, material/environment/ColorEnvironment.cpp:6-9 */
+    int32_t has_environment; /* 0: none; 1: ColorEnvironment (material/environment/ColorEnvironment.cpp:6-9), radiance =
+                              * env_color * env_intensity; 2: ImageMapEnvironment (ImageMapEnvironment.cpp:15-23), radiance =
+                              * the texel of env_map at the direction's longitude / latitude * env_intensity */
     float env_color[3];
     double env_intensity;
     const rtgpu_directional_light* directional_lights; /* may be null when n_directional_lights == 0 */
     uint32_t n_directional_lights;
     uint32_t n_textures;
     const rtgpu_texture* textures; /* may be null when n_textures == 0 */
+    /* Texture<float> of the ImageMapEnvironment (material/Texture.h, divisor 1, gamma 1): RGBA floats, rows top to bottom
+     * (what read_hdr_file returns, io/HDR.cpp:5-18); read only when has_environment == 2 */
+    const float* env_map;
+    uint32_t env_map_width;
+    uint32_t env_map_height;
 } rtgpu_scene_desc;
 
 typedef struct rtgpu_scene rtgpu_scene;
@@ -342,6 +349,10 @@ int rtgpu_scene_gather_photons(const rtgpu_scene* scene, const float* points, co
  * follows from the file's yfov).  PNG images only; no GPU is touched. */
 typedef struct rtgpu_gltf rtgpu_gltf;
 int rtgpu_gltf_load(const char* glb_path, float image_aspect_ratio, int soupify, rtgpu_gltf** out);
+/* PathResolver::setWorkDir (utility/PathResolver.cpp:22-24, set from --workdir in exe/Raytracer.cpp:112): what "#WORKDIR#"
+ * stands for in a path the file names (the scene's "EnvironmentHDRIFilePath").  Process-wide like the reference's
+ * singleton; empty until set.  Call before rtgpu_gltf_load. */
+void rtgpu_gltf_set_workdir(const char* directory);
 /* The description to hand to rtgpu_scene_create; its arrays live until rtgpu_gltf_free. */
 const rtgpu_scene_desc* rtgpu_gltf_scene_desc(const rtgpu_gltf* g);
 /* Renderer::findCamera (renderer/Renderer.cpp:304-320): the last camera whose node (or parent) carries

@@ -616,8 +616,11 @@ struct orc_scene {
     std::vector<rtgpu_directional_light> dirLights;
     struct Tex { std::vector<uint8_t> rgba; uint32_t width, height; double gamma; };
     std::vector<Tex> textures;
-    bool hasEnv = false;
+    int hasEnv = 0;   // 0 none, 1 ColorEnvironment, 2 ImageMapEnvironment
     RGBf envRadiance; // color * intensity, ColorEnvironment.cpp:6-9
+    std::vector<float> envMap;   // Texture<float>: RGBA, rows top to bottom
+    uint32_t envW = 0, envH = 0;
+    double envIntensity = 0.0;
     // Scene::photonMap / photonMapMode / photonMapDepth: photons + the tree of photonmapping/KDTreeBuilder.h
     std::vector<rtgpu_photon> photons;
     struct KdNode { int32_t child[2]; uint32_t photon; int32_t axis; };
@@ -1685,12 +1688,30 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
     return pathTerminated;
 }
 
+// IEnvironmentMaterial::getRadiance: ColorEnvironment.cpp:6-9 or ImageMapEnvironment.cpp:15-23 (float asin / cos / atan2 of
+// the float direction, the rest in double; Texture<float>::get divides by 1 and raises to gamma 1).  Indices that fall
+// outside the image (the reference would read past it: straight down, the seam) are clamped; NaN reads column / row 0.
+RGBf env_radiance(const orc_scene& S, V3 dir)
+{
+    if (S.hasEnv != 2) return S.envRadiance;
+    const float latitude = std::asin(dir.y);
+    const float cl = std::cos(latitude);
+    const double longitude = M_PI + std::atan2(dir.z / cl, dir.x / cl);
+    const double x = S.envW * longitude / (2.0f * M_PI);
+    const double y = S.envH * (1.0f - (((M_PI / 2.0f) + latitude) / M_PI));
+    int xi = x == x ? (int)x : 0, yi = y == y ? (int)y : 0;
+    xi = std::min(std::max(xi, 0), (int)S.envW - 1);
+    yi = std::min(std::max(yi, 0), (int)S.envH - 1);
+    const float* t = &S.envMap[((size_t)yi * S.envW + (size_t)xi) * 4];
+    return rgb_scale_d(RGBf{t[0] / 1.0f, t[1] / 1.0f, t[2] / 1.0f}, S.envIntensity);
+}
+
 // calculatePathEnergy, renderer/Renderer.cpp:89-109
 RGBf path_energy(const orc_scene& S, const std::vector<TransportNode>& path)
 {
     const TransportNode& last = path.back();
     RGBf energy;
-    if (S.hasEnv && !last.isEmissive) energy = S.envRadiance;
+    if (S.hasEnv && !last.isEmissive) energy = env_radiance(S, last.transportDirection);
     for (int i = (int)path.size() - 1; i >= 0; --i) {
         const TransportNode& n = path[i];
         energy = mat_bsdf(S, n, energy);
@@ -1786,7 +1807,7 @@ RGBf render_pixel(RenderCtx& R, const rtgpu_camera& cam, const rtgpu_render_sett
             }
         }
         if (!hit.ok) {
-            if (S.hasEnv) pixelValue = rgb_add(pixelValue, S.envRadiance);
+            if (S.hasEnv) pixelValue = rgb_add(pixelValue, env_radiance(S, rd));
             continue;
         }
         TransportNode n0;
@@ -2037,7 +2058,12 @@ orc_scene* orc_scene_create(const rtgpu_scene_desc* desc, int n_threads)
         S->textures.push_back({std::vector<uint8_t>(t.rgba, t.rgba + (size_t)t.width * t.height * 4), t.width, t.height, t.gamma});
     }
     if (desc->n_directional_lights) S->dirLights.assign(desc->directional_lights, desc->directional_lights + desc->n_directional_lights);
-    S->hasEnv = desc->has_environment != 0;
+    S->hasEnv = desc->has_environment;
+    if (desc->has_environment == 2) {
+        S->envW = desc->env_map_width; S->envH = desc->env_map_height;
+        S->envMap.assign(desc->env_map, desc->env_map + (size_t)S->envW * S->envH * 4);
+        S->envIntensity = desc->env_intensity;
+    }
     S->envRadiance = rgb_scale_d(RGBf{desc->env_color[0], desc->env_color[1], desc->env_color[2]}, desc->env_intensity);
     return S;
 }

@@ -78,7 +78,8 @@ class SceneDesc(C.Structure):
                 ("n_point_lights", C.c_uint32), ("n_area_lights", C.c_uint32),
                 ("has_environment", C.c_int32), ("env_color", C.c_float * 3), ("env_intensity", C.c_double),
                 ("directional_lights", C.POINTER(DirectionalLight)), ("n_directional_lights", C.c_uint32),
-                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture))]
+                ("n_textures", C.c_uint32), ("textures", C.POINTER(Texture)),
+                ("env_map", C.POINTER(C.c_float)), ("env_map_width", C.c_uint32), ("env_map_height", C.c_uint32)]
 
 
 class Hit(C.Structure):
@@ -160,6 +161,7 @@ class SceneData:
     directional_lights: List[tuple] = field(default_factory=list)  # (direction3, angle, color3, intensity)
     textures: List[tuple] = field(default_factory=list)       # ((h, w, 4) uint8 pixels, gamma)
     env: Optional[tuple] = None                               # (color3, intensity)
+    env_map: Optional[tuple] = None                           # ((height, width, 4) float32 texels, intensity): an image-map environment
 
     def n_triangles(self) -> int:
         return int(sum(m.indices.shape[0] for m in self.meshes))
@@ -268,6 +270,15 @@ class PackedScene:
             d.has_environment = 1
             d.env_color[:] = [float(x) for x in scene.env[0]]
             d.env_intensity = float(scene.env[1])
+        if scene.env_map is not None:
+            texels = np.ascontiguousarray(scene.env_map[0], dtype=np.float32)
+            if texels.ndim != 3 or texels.shape[2] != 4:
+                raise ValueError("environment texels must have shape (height, width, 4)")
+            self._keep.append(texels)
+            d.has_environment = 2
+            d.env_map = texels.ctypes.data_as(C.POINTER(C.c_float))
+            d.env_map_height, d.env_map_width = texels.shape[0], texels.shape[1]
+            d.env_intensity = float(scene.env_map[1])
         self.desc = d
 
 

@@ -26,7 +26,7 @@ EXPORTS = [
     "rtgpu_trace_closest", "rtgpu_trace_closest_device", "rtgpu_trace_any", "rtgpu_trace_any_device",
     "rtgpu_generate_primary_device", "rtgpu_render", "rtgpu_render_device", "rtgpu_camera_from_transform",
     "rtgpu_scene_get_info", "rtgpu_trace_closest_count_device",
-    "rtgpu_gltf_load", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
+    "rtgpu_gltf_load", "rtgpu_gltf_set_workdir", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
     "rtgpu_write_exr", "rtgpu_write_png",
     "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
 ]

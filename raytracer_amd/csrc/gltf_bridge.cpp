@@ -4,7 +4,7 @@
 // :323-455, lights and camera parameters from node "extras", the environment from scene "extras")
 // and the flattening of DynamicScene::build / soupifyScene (scene/dynamic/DynamicScene.cpp:17-160).
 // The reference parses with tinygltf + stb_image (third-party, vendored there); here the container,
-// the JSON and PNG images (zlib) are read directly.  JPEG images, HDR environment maps and
+// the JSON, PNG images (zlib) and Radiance .hdr environment maps are read directly.  JPEG images and
 // "VideoImageMapping" materials have no decoder here and are reported as unsupported.
 // Host code only: nothing in this file touches the GPU.
 #include <zlib.h>
@@ -439,6 +439,102 @@ void decode_png(const uint8_t* data, size_t n, std::vector<uint8_t>& rgba, uint3
     }
 }
 
+// Radiance .hdr -> RGBA floats, what read_hdr_file (io/HDR.cpp:5-18) gets from stb_image's stbi_loadf with 4
+// components.  stb_image's rules, from its source text (io/lib/stb_image.h, stbi__hdr_load / stbi__hdr_convert): the
+// first line is "#?RADIANCE" or "#?RGBE", a header line "FORMAT=32-bit_rle_rgbe" is required, the size line is
+// "-Y <height> +X <width>"; rows are run-length coded per component when 8 <= width < 32768 and the row starts with
+// 2 2 <width, 2 bytes>, flat RGBE otherwise; a pixel is mantissa * 2^(e - 136) in float, (0, 0, 0) for e = 0, alpha 1.
+// (A flat row met after coded rows makes stb_image restart at the first row; such a file is refused here.)
+void decode_hdr(const std::vector<uint8_t>& file, std::vector<float>& rgba, uint32_t& width, uint32_t& height)
+{
+    size_t pos = 0;
+    auto line = [&]() {
+        std::string t;
+        while (pos < file.size() && file[pos] != '\n') t.push_back((char)file[pos++]);
+        if (pos < file.size()) ++pos;
+        return t;
+    };
+    const std::string magic = line();
+    if (magic != "#?RADIANCE" && magic != "#?RGBE") throw std::runtime_error("Failed to load HDR file");
+    bool valid = false;
+    for (;;) {
+        const std::string t = line();
+        if (t.empty()) break;
+        if (t == "FORMAT=32-bit_rle_rgbe") valid = true;
+    }
+    if (!valid) throw std::runtime_error("Failed to load HDR file");
+    const std::string size = line();
+    if (size.compare(0, 3, "-Y ") != 0) throw std::runtime_error("Failed to load HDR file");
+    char* end = nullptr;
+    const long h = std::strtol(size.c_str() + 3, &end, 10);
+    while (*end == ' ') ++end;
+    if (std::strncmp(end, "+X ", 3) != 0) throw std::runtime_error("Failed to load HDR file");
+    const long w = std::strtol(end + 3, nullptr, 10);
+    if (w <= 0 || h <= 0 || (uint64_t)w * (uint64_t)h >= (1ull << 28)) throw std::runtime_error("Failed to load HDR file");
+    width = (uint32_t)w; height = (uint32_t)h;
+    rgba.assign((size_t)w * h * 4, 0.0f);
+    auto need = [&](size_t n) { if (pos + n > file.size()) throw std::runtime_error("Failed to load HDR file"); };
+    auto convert = [&](const uint8_t* in, float* out) {
+        if (in[3] != 0) {
+            const float f1 = (float)std::ldexp(1.0f, (int)in[3] - (int)(128 + 8));
+            out[0] = in[0] * f1; out[1] = in[1] * f1; out[2] = in[2] * f1;
+        } else {
+            out[0] = out[1] = out[2] = 0.0f;
+        }
+        out[3] = 1.0f;
+    };
+    const bool mayBeCoded = w >= 8 && w < 32768;
+    bool flat = !mayBeCoded;
+    if (mayBeCoded) {
+        need(4);
+        flat = file[pos] != 2 || file[pos + 1] != 2 || (file[pos + 2] & 0x80);   // decided by the first row
+    }
+    if (flat) {
+        need((size_t)w * h * 4);
+        for (size_t i = 0; i < (size_t)w * h; ++i) convert(&file[pos + 4 * i], &rgba[4 * i]);
+        return;
+    }
+    std::vector<uint8_t> scan((size_t)w * 4);
+    for (long j = 0; j < h; ++j) {
+        need(4);
+        if (file[pos] != 2 || file[pos + 1] != 2 || (file[pos + 2] & 0x80)) throw std::runtime_error("Failed to load HDR file");
+        const long len = ((long)file[pos + 2] << 8) | file[pos + 3];
+        pos += 4;
+        if (len != w) throw std::runtime_error("Failed to load HDR file");
+        for (int k = 0; k < 4; ++k) {
+            long i = 0;
+            while (w - i > 0) {
+                need(1);
+                int count = file[pos++];
+                if (count > 128) {
+                    need(1);
+                    const uint8_t value = file[pos++];
+                    count -= 128;
+                    if (count > w - i) throw std::runtime_error("Failed to load HDR file");
+                    for (int z = 0; z < count; ++z) scan[(size_t)(i++) * 4 + k] = value;
+                } else {
+                    if (count > w - i) throw std::runtime_error("Failed to load HDR file");
+                    if (count == 0) throw std::runtime_error("Failed to load HDR file");   // would never end
+                    need((size_t)count);
+                    for (int z = 0; z < count; ++z) scan[(size_t)(i++) * 4 + k] = file[pos++];
+                }
+            }
+        }
+        for (long i = 0; i < w; ++i) convert(&scan[(size_t)i * 4], &rgba[((size_t)j * w + i) * 4]);
+    }
+}
+
+// PathResolver (utility/PathResolver.cpp): "#WORKDIR#" in a path stands for the directory set with setWorkDir
+std::string g_workdir;
+std::string resolve_path(const std::string& in)
+{
+    std::string str = in;
+    size_t at;
+    if (g_workdir.find("#WORKDIR#") != std::string::npos) return str;   // the replacement would never end
+    while ((at = str.find("#WORKDIR#")) != std::string::npos) str.replace(at, 9, g_workdir);
+    return str;
+}
+
 std::vector<uint8_t> read_file(const std::string& path)
 {
     std::ifstream f(path, std::ios::binary);
@@ -477,9 +573,11 @@ struct rtgpu_gltf {
     std::vector<rtgpu_directional_light> dirLights;
     std::vector<std::unique_ptr<Tex>> textures;
     std::vector<Camera> cameras;
-    bool hasEnv = false;
+    int hasEnv = 0;   // 1: colour, 2: image map
     float envColor[3] = {0, 0, 0};
     double envIntensity = 0;
+    std::vector<float> envMap;
+    uint32_t envW = 0, envH = 0;
     // views handed to the caller
     std::vector<rtgpu_mesh_desc> meshDescs;
     std::vector<rtgpu_texture> texDescs;
@@ -854,11 +952,21 @@ struct Loader {
         const Json* extras = scene.find("extras");
         const double intensity = extras_double(extras, "EnvironmentIntensity", 0.0);
         if (!(intensity > 0)) return;
-        if (extras->has("EnvironmentHDRIFilePath")) throw Unsupported("HDR environment maps are not supported");
-        if (extras->has("EnvironmentColor")) {
+        if (extras->has("EnvironmentHDRIFilePath")) {
+            const std::string hdrPath = extras->get_str("EnvironmentHDRIFilePath");
+            std::vector<uint8_t> file;
+            try {
+                file = read_file(resolve_path(hdrPath));
+            } catch (const std::exception&) {
+                throw std::runtime_error("Failed to load HDR file");   // io/HDR.cpp:10-13
+            }
+            decode_hdr(file, out.envMap, out.envW, out.envH);
+            out.envIntensity = intensity;
+            out.hasEnv = 2;
+        } else if (extras->has("EnvironmentColor")) {
             extras_color(extras, "EnvironmentColor", out.envColor);
             out.envIntensity = intensity;
-            out.hasEnv = true;
+            out.hasEnv = 1;
         }
     }
 
@@ -985,7 +1093,10 @@ void finish(rtgpu_gltf& g)
     d.area_lights = g.areaLights.data(); d.n_area_lights = (uint32_t)g.areaLights.size();
     d.directional_lights = g.dirLights.data(); d.n_directional_lights = (uint32_t)g.dirLights.size();
     d.textures = g.texDescs.data(); d.n_textures = (uint32_t)g.texDescs.size();
-    d.has_environment = g.hasEnv ? 1 : 0;
+    d.has_environment = g.hasEnv;
+    d.env_map = g.envMap.empty() ? nullptr : g.envMap.data();
+    d.env_map_width = g.envW;
+    d.env_map_height = g.envH;
     std::memcpy(d.env_color, g.envColor, 12);
     d.env_intensity = g.envIntensity;
 }
@@ -993,6 +1104,8 @@ void finish(rtgpu_gltf& g)
 } // namespace
 
 extern "C" {
+
+void rtgpu_gltf_set_workdir(const char* directory) { g_workdir = directory ? directory : ""; }
 
 int rtgpu_gltf_load(const char* glb_path, float image_aspect_ratio, int soupify_scene, rtgpu_gltf** out)
 {

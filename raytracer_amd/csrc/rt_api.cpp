@@ -111,6 +111,12 @@ int validate(const rtgpu_scene_desc* d)
         if (!affine(id.transform) || !affine(id.inverse))
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance transforms must be affine (last row 0 0 0 1)");
     }
+    if (d->has_environment < 0 || d->has_environment > 2) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown environment type");
+    if (d->has_environment == 2) {
+        // Texture's constructor checks the buffer size (material/Texture.h:18-21)
+        if (!d->env_map || d->env_map_width == 0 || d->env_map_height == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "environment map without pixels");
+        if ((uint64_t)d->env_map_width * d->env_map_height >= (1ull << 28)) return fail(RTGPU_ERR_LIMIT, "environment map larger than 2^28 pixels");
+    }
     if (d->n_textures && !d->textures) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null texture array");
     for (uint32_t i = 0; i < d->n_textures; ++i) {
         const rtgpu_texture& t = d->textures[i];
@@ -202,7 +208,7 @@ void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
-                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.kdPos, view.kdNormal, view.kdEnergy};
+                          view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.envMap, view.kdPos, view.kdNormal, view.kdEnergy};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
     view = rt::SceneView{};
@@ -525,6 +531,12 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "directional light with a zero direction");
     }
 
+    std::vector<float4> envTexels;
+    if (desc->has_environment == 2) {
+        envTexels.resize((size_t)desc->env_map_width * desc->env_map_height);
+        std::memcpy(envTexels.data(), desc->env_map, envTexels.size() * sizeof(float4));
+    }
+
     const auto t1 = std::chrono::steady_clock::now();
     info.build_ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
 
@@ -544,7 +556,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
         (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes)) ||
         (rc = upload(vertUV, &v.vertUV, bytes)) || (rc = upload(texs, &v.textures, bytes)) || (rc = upload(texels, &v.texels, bytes)) ||
-        (rc = upload(instFwd, &v.instFwd, bytes))) {
+        (rc = upload(instFwd, &v.instFwd, bytes)) || (rc = upload(envTexels, &v.envMap, bytes))) {
         sc->release();
         delete sc;
         return rc;
@@ -568,7 +580,10 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nPointLights = desc->n_point_lights;
     v.nAreaLights = desc->n_area_lights;
     v.nDirLights = desc->n_directional_lights;
-    v.hasEnv = desc->has_environment ? 1 : 0;
+    v.hasEnv = desc->has_environment;
+    v.envW = desc->env_map_width;
+    v.envH = desc->env_map_height;
+    v.envIntensity = desc->env_intensity;
     for (uint32_t i = 0; i < desc->n_materials; ++i) {
         if (desc->materials[i].type == RTGPU_MAT_FRESNELMIX) v.hasFresnelMix = 1;
         if (desc->materials[i].type == RTGPU_MAT_GLASS) v.hasGlass = 1;

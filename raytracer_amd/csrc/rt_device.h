@@ -94,6 +94,9 @@ struct SceneView {
     int32_t pmMode;             // rtgpu_photon_map_mode
     int32_t pmDepth;
     float envRadiance[3];
+    const float4* envMap;       // hasEnv == 2: the environment's texels (RGBA floats, rows top to bottom)
+    uint32_t envW, envH;
+    double envIntensity;
 };
 
 // Closest hit for n rays (Scene::traceRay).  counts may be null.

@@ -204,7 +204,7 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
             value = rgb_scale_f(area_light_irradiance(sv.areaLights[light]), 1.0f / (float)2); // .divide(2)
             live = false;
         } else if (!hit) {
-            if (sv.hasEnv) value = rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]); // Renderer.cpp:217-225
+            if (sv.hasEnv) value = env_radiance(sv, d); // Renderer.cpp:217-225
             live = false;
         }
     }
@@ -377,7 +377,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         // the reference traces the same ray once more (Renderer.cpp:57-61) and it misses again
                         done = true;
                         completed = true;
-                        if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
+                        if (sv.hasEnv) result = rgb_mul(thr, env_radiance(sv, d));
                     } else {
                         k += 1;
                         state = (state & ~ST_K_MASK) | (uint32_t)k;
@@ -389,7 +389,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             if (!hit) {
                 done = true;
                 completed = true;
-                if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
+                if (sv.hasEnv) result = rgb_mul(thr, env_radiance(sv, d));
             } else {
                 k += 1;
                 state = (state & ~ST_K_MASK) | (uint32_t)k;
@@ -399,7 +399,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             // the environment along its transport direction (renderer/Renderer.cpp:73-76, 94-98)
             done = true;
             completed = true;
-            if (sv.hasEnv) result = rgb_mul(thr, rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]));
+            if (sv.hasEnv) result = rgb_mul(thr, env_radiance(sv, d));
         }
 
         if (!done) {

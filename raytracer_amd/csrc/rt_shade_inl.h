@@ -286,6 +286,26 @@ __device__ __forceinline__ RGBf emission_lookup(const SceneView& sv, uint32_t te
     return texture_get(sv, texture, fabsf(fmodf(u, 1.0f)), fabsf(fmodf(v, 1.0f)));
 }
 
+// IEnvironmentMaterial::getRadiance along `dir`: ColorEnvironment (material/environment/ColorEnvironment.cpp:6-9) or
+// ImageMapEnvironment (ImageMapEnvironment.cpp:15-23: latitude = asin(y), longitude = pi + atan2(z / cos, x / cos) in
+// float, texel (int)(width * longitude / 2 pi), (int)(height * (1 - (pi / 2 + latitude) / pi)) of a Texture<float>,
+// times the intensity).  Indices the reference would read outside the image with (straight up or down, the seam) are
+// clamped to it; a direction along the y axis (0 / 0 in the longitude) reads column 0.
+__device__ __forceinline__ RGBf env_radiance(const SceneView& sv, F3 dir)
+{
+    if (sv.hasEnv != 2) return rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]);
+    const float latitude = asinf(dir.y);
+    const float cl = cosf(latitude);
+    const double longitude = RT_PI + (double)atan2f(dir.z / cl, dir.x / cl);
+    const double x = (double)sv.envW * longitude / (2.0f * RT_PI);
+    const double y = (double)sv.envH * (1.0f - (((RT_PI / 2.0f) + (double)latitude) / RT_PI));
+    int xi = x == x ? (int)x : 0, yi = y == y ? (int)y : 0;
+    xi = xi < 0 ? 0 : (xi > (int)sv.envW - 1 ? (int)sv.envW - 1 : xi);
+    yi = yi < 0 ? 0 : (yi > (int)sv.envH - 1 ? (int)sv.envH - 1 : yi);
+    const float4 t = sv.envMap[(size_t)yi * sv.envW + (size_t)xi];
+    return rgb_scale_d(rgb(t.x / 1.0f, t.y / 1.0f, t.z / 1.0f), sv.envIntensity);   // Texture::get: / divisor, pow(gamma = 1)
+}
+
 // sample_normal_map (material/NormalMapSampler.h:7-21) at a triangle hit.  The hit's tangent is row 0 of
 // uvMat^-1 * deltaPosMat (shape/TriangleMesh.cpp:130-139; 2x2 inverse = adjugate / determinant), taken to
 // world space as a vector (shape/list/InstancedModelList.cpp:131); tangentToObject (math/Transformation.cpp:

@@ -33,6 +33,8 @@ def _lib():
         L.rtgpu_gltf_camera_count.restype = C.c_uint32
         L.rtgpu_gltf_free.argtypes = [C.c_void_p]
         L.rtgpu_gltf_free.restype = None
+        L.rtgpu_gltf_set_workdir.argtypes = [C.c_char_p]
+        L.rtgpu_gltf_set_workdir.restype = None
         L._gltf_ready = True
     return L
 
@@ -108,9 +110,48 @@ class GltfScene:
             t = d.textures[i]
             px = np.ctypeslib.as_array(t.rgba, shape=(int(t.height), int(t.width), 4)).copy()
             sc.textures.append((px, float(t.gamma)))
-        if d.has_environment:
+        if d.has_environment == 1:
             sc.env = (tuple(d.env_color[:]), float(d.env_intensity))
+        elif d.has_environment == 2:
+            n = int(d.env_map_height) * int(d.env_map_width) * 4
+            texels = np.ctypeslib.as_array(d.env_map, shape=(n,)).reshape(int(d.env_map_height), int(d.env_map_width), 4).copy()
+            sc.env_map = (texels, float(d.env_intensity))
         return sc
+
+
+def set_workdir(directory):
+    """PathResolver::setWorkDir: what "#WORKDIR#" stands for in the paths a file names (process-wide)."""
+    _lib().rtgpu_gltf_set_workdir(str(directory).encode())
+
+
+def encode_hdr(pixels_rgbe, coded=True) -> bytes:
+    """A Radiance .hdr file of (height, width, 4) RGBE bytes: per-component run-length coded rows when `coded` and
+    8 <= width < 32768, flat otherwise."""
+    px = np.ascontiguousarray(pixels_rgbe, dtype=np.uint8)
+    h, w = px.shape[:2]
+    out = bytearray(b"#?RADIANCE\nFORMAT=32-bit_rle_rgbe\n\n" + ("-Y %d +X %d\n" % (h, w)).encode())
+    if not (coded and 8 <= w < 32768):
+        return bytes(out) + px.tobytes()
+    for y in range(h):
+        out += bytes([2, 2, w >> 8, w & 255])
+        for k in range(4):
+            row = px[y, :, k]
+            i = 0
+            while i < w:
+                run = 1
+                while i + run < w and run < 127 and row[i + run] == row[i]:
+                    run += 1
+                if run >= 3:
+                    out += bytes([128 + run, int(row[i])])
+                    i += run
+                else:
+                    j = i
+                    while j < w and j - i < 128 and not (j + 2 < w and row[j] == row[j + 1] == row[j + 2]):
+                        j += 1
+                    j = max(j, i + 1)
+                    out += bytes([j - i]) + row[i:j].tobytes()
+                    i = j
+    return bytes(out)
 
 
 def load_glb(path, image_aspect_ratio=1.0, soupify=False) -> GltfScene:

@@ -371,6 +371,52 @@ def test_png_files_the_reference_refuses(tmp_path):
             _texture_of(png, tmp_path)
 
 
+def _env_scene(tmp_path, hdr_bytes, hdr_name="#WORKDIR#/sky.hdr", intensity=1.5):
+    open(os.path.join(str(tmp_path), "sky.hdr"), "wb").write(hdr_bytes)
+    b = gltf.GlbBuilder()
+    us = scenes.uv_sphere(12, 6)
+    b.add_node(mesh=b.add_primitive_mesh([(us.vertices, us.normals, us.indices, None, None)]))
+    cam_m = scenes.look_at((0.0, 0.5, 4.0), (0.0, 0.0, 0.0))
+    b.add_node(camera=b.add_camera(0.8), matrix=[float(x) for x in np.asarray(cam_m).T.reshape(-1)])
+    b.set_scene_extras(EnvironmentIntensity=intensity, EnvironmentHDRIFilePath=hdr_name, EnvironmentColor=[1, 0, 0])
+    path = os.path.join(str(tmp_path), "env.glb")
+    b.write(path)
+    return path
+
+
+def test_hdr_environment_map_of_a_file(tmp_path):
+    """loadEnvironmentInfo with "EnvironmentHDRIFilePath" (io/GLTF.cpp:640-660): the Radiance file is found through the
+    work directory ("#WORKDIR#", utility/PathResolver.cpp) and read as stb_image reads it for read_hdr_file
+    (io/HDR.cpp:5-18; rules read from io/lib/stb_image.h stbi__hdr_load / stbi__hdr_convert: mantissa * 2^(e - 136),
+    black for e = 0, alpha 1; run-length coded rows for 8 <= width < 32768, flat rows otherwise).  The HDR file wins
+    over "EnvironmentColor".  The reference's decoder could not be run here: parity unpinned, the test pins the rules."""
+    rng = np.random.RandomState(4)
+    gltf.set_workdir(str(tmp_path))
+    try:
+        for (w, h, coded) in ((16, 6, True), (16, 6, False), (5, 3, True), (40, 9, True)):
+            rgbe = rng.randint(0, 256, size=(h, w, 4)).astype(np.uint8)
+            rgbe[..., 3] = rng.randint(120, 140, size=(h, w))
+            rgbe[0, 0, 3] = 0                                   # e = 0: black whatever the mantissas
+            rgbe[1, 2:9 if w > 9 else 3] = rgbe[1, 2]           # a run
+            with gltf.load_glb(_env_scene(tmp_path, gltf.encode_hdr(rgbe, coded))) as g:
+                sc = g.scene_data()
+            texels, intensity = sc.env_map
+            assert sc.env is None and intensity == 1.5 and texels.shape == (h, w, 4)
+            f = np.ldexp(np.float32(1.0), rgbe[..., 3].astype(np.int32) - 136).astype(np.float32)
+            want = rgbe[..., :3].astype(np.float32) * f[..., None]
+            want[rgbe[..., 3] == 0] = 0
+            assert np.array_equal(texels[..., :3], want) and np.all(texels[..., 3] == 1.0)
+        # failures: io/HDR.cpp:10-13 "Failed to load HDR file"
+        good = gltf.encode_hdr(rng.randint(1, 256, size=(4, 16, 4)).astype(np.uint8))
+        for bad in (good[:60], good.replace(b"32-bit_rle_rgbe", b"32-bit_rle_xyze"), good.replace(b"-Y 4 +X 16", b"+Y 4 +X 16"), b"P6\n"):
+            with pytest.raises(api.RtgpuError, match="Failed to load HDR file"):
+                gltf.load_glb(_env_scene(tmp_path, bad))
+        with pytest.raises(api.RtgpuError, match="Failed to load HDR file"):
+            gltf.load_glb(_env_scene(tmp_path, good, hdr_name="#WORKDIR#/missing.hdr"))
+    finally:
+        gltf.set_workdir("")
+
+
 def _render_scene(tmp_path):
     """A small room exported to .glb: instanced spheres under a scaled parent, textured floor, lights from extras."""
     b = gltf.GlbBuilder()

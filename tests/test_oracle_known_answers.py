@@ -453,3 +453,45 @@ def test_normal_map_turns_the_shading_normal_into_the_tangent_frame():
         assert np.allclose(images[mapped].reshape(-1, 3).mean(axis=0), want, rtol=0.03), mapped
     assert images[True].mean() > 10 * images[False].mean()
     assert np.allclose(images["plain"], images[True], rtol=1e-5)
+
+
+def test_image_map_environment_is_read_at_the_longitude_and_latitude_of_the_ray():
+    """ImageMapEnvironment::getRadiance (material/environment/ImageMapEnvironment.cpp:15-23): latitude = asin(y),
+    longitude = pi + atan2(z / cos(latitude), x / cos(latitude)), texel column = (int)(width * longitude / 2 pi), row =
+    (int)(height * (1 - (pi / 2 + latitude) / pi)), times the intensity.  A camera inside an empty scene (one far,
+    tiny triangle) sees exactly that texel per pixel; rows run from straight up (row 0) to straight down, and
+    direction +x reads the middle column (longitude pi)."""
+    from raytracer_amd.abi import MAT_DIFFUSE, InstanceData, MaterialData, MeshData, SceneData
+    rng = np.random.RandomState(6)
+    h, w = 8, 16
+    texels = np.ones((h, w, 4), np.float32)
+    texels[..., :3] = rng.uniform(0.0, 4.0, size=(h, w, 3)).astype(np.float32)
+    sc = SceneData()
+    v = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
+    sc.meshes = [MeshData(v, np.tile(np.array([[0, 0, 1]], np.float32), (3, 1)), np.array([[0, 1, 2]], np.uint32))]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.5, 0.5, 0.5))]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    sc.env_map = (texels, 2.5)
+    S = oracle.OracleScene(sc)
+    W = H = 24
+    seen = set()
+    for cam_m in (np.eye(4), scenes.look_at((0, 0, 0), (1.0, 0.4, 0.2)), scenes.look_at((0, 0, 0), (-0.3, -1.0, 0.5)), scenes.look_at((0, 0, 0), (0.1, 1.0, -0.2))):
+        cam = oracle.camera_from_transform(100.0, cam_m)
+        st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+        img, _ = S.render(cam, st)
+        o, d = oracle.generate_primary(cam, st)
+        d = d.reshape(H, W, 3).astype(np.float32)
+        lat = np.arcsin(d[..., 1])
+        cl = np.cos(lat)
+        lon = np.pi + np.arctan2(d[..., 2] / cl, d[..., 0] / cl).astype(np.float64)
+        col = np.clip((w * lon / (2 * np.pi)).astype(int), 0, w - 1)
+        row = np.clip((h * (1.0 - ((np.pi / 2 + lat.astype(np.float64)) / np.pi))).astype(int), 0, h - 1)
+        want = (texels[row, col, :3].astype(np.float64) * 2.5).astype(np.float32)
+        same = np.isclose(img, want, rtol=1e-6).all(-1)
+        assert same.mean() > 0.99        # a direction within an ulp of a texel border may round to the neighbour
+        seen |= set(zip(row.reshape(-1).tolist(), col.reshape(-1).tolist()))
+    assert len(seen) > 0.6 * h * w       # the views cover most of the sphere, up and down included
+    # along +x: latitude 0 (row height / 2), longitude pi (column width / 2)
+    cam = oracle.camera_from_transform(1.0, scenes.look_at((0, 0, 0), (1.0, 0.0, 0.0)))
+    img, _ = S.render(cam, abi.make_settings(1, 1, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER))
+    assert np.allclose(img[0, 0], texels[h // 2, w // 2, :3] * 2.5, rtol=1e-6)
