@@ -1,5 +1,6 @@
 // Host-only harness: the .glb loader (raytracer_amd/csrc/gltf_bridge.cpp, compiled in here) on randomly damaged
 // copies of a valid file, for a build with -fsanitize=address,undefined.  Usage: fuzz_gltf <valid.glb> <scratch.glb> <n>
+// or, to damage the Radiance .hdr file a scene names instead: fuzz_gltf <valid.hdr> <the .hdr path the .glb names> <n> <scene.glb>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -28,7 +29,7 @@ int main(int argc, char** argv)
         if (k % 5 == 0) d.resize(12 + rng() % (d.size() - 12));
         std::ofstream o(scratch, std::ios::binary); o.write(d.data(), d.size()); o.close();
         rtgpu_gltf* g = nullptr;
-        if (rtgpu_gltf_load(scratch.c_str(), 1.5f, k & 1, &g) == 0) { rtgpu_camera c; rtgpu_gltf_camera(g, &c); rtgpu_gltf_free(g); ++ok; } else ++err;
+        if (rtgpu_gltf_load(argc > 4 ? argv[4] : scratch.c_str(), 1.5f, k & 1, &g) == 0) { rtgpu_camera c; rtgpu_gltf_camera(g, &c); rtgpu_gltf_free(g); ++ok; } else ++err;
     }
     std::printf("ok %d err %d\n", ok, err);
 }

@@ -621,3 +621,14 @@ def test_loader_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     run = subprocess.run([exe, path, os.path.join(str(tmp_path), "scratch.glb"), "1500"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
     assert "ok " in run.stdout and "err " in run.stdout
+    # the Radiance reader: a scene that names scratch.hdr, damaged copies of a run-length coded file written there
+    rng = np.random.RandomState(9)
+    rgbe = rng.randint(0, 256, size=(12, 24, 4)).astype(np.uint8)
+    rgbe[3:6, 4:20] = rgbe[3, 4]
+    good = os.path.join(str(tmp_path), "good.hdr")
+    open(good, "wb").write(gltf.encode_hdr(rgbe))
+    scene = _env_scene(tmp_path, b"", hdr_name=os.path.join(str(tmp_path), "scratch.hdr"))
+    run = subprocess.run([exe, good, os.path.join(str(tmp_path), "scratch.hdr"), "1500", scene], capture_output=True, text=True, timeout=600)
+    assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
+    ok, err = [int(x) for x in run.stdout.split()[1::2]]
+    assert ok > 100 and err > 100
