@@ -197,7 +197,7 @@ def main():
     # VALU wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU): each occupies a SIMD's issue port
     # for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs at 2.4 GHz
     valu_issue = None
-    ppath = os.path.join(HERE, "profiles", "r01e_pmc_summary.json")
+    ppath = os.path.join(HERE, "profiles", "r01f_pmc_summary.json")
     if os.path.exists(ppath) and (args.width, args.height, args.subdiv) == (1920, 1080, 8):
         try:
             valu = json.load(open(ppath))["per_launch"]["SQ_INSTS_VALU"]["mean"]
