@@ -21,8 +21,12 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
 #include <thread>
 #include <vector>
@@ -264,23 +268,41 @@ __global__ __launch_bounds__(64) void gather_tail_kernel(SceneView sv, const flo
     }
 }
 
-// Permutes idx[lo, hi) so that every range has its median along axis (depth + 1) % 3 in the middle.
-void kd_order(const std::vector<rtgpu_photon>& ph, uint32_t* idx, size_t lo, size_t hi, uint32_t depth, int spawnLevels)
+// Position and index of a photon, 16 bytes: what the ordering moves around (the photons themselves stay where they are).
+struct KdKey { float pos[3]; uint32_t index; };
+
+// Permutes keys[lo, hi) so that every range has its median along axis (depth + 1) % 3 in the middle.
+void kd_order(KdKey* keys, size_t lo, size_t hi, uint32_t depth, int spawnLevels)
 {
     while (hi - lo > 1) {
         const size_t mid = lo + (hi - lo) / 2;
         const int axis = (int)((depth + 1u) % 3u);
-        std::nth_element(idx + lo, idx + mid, idx + hi, [&](uint32_t a, uint32_t b) { return ph[a].pos[axis] < ph[b].pos[axis]; });
+        std::nth_element(keys + lo, keys + mid, keys + hi, [axis](const KdKey& a, const KdKey& b) { return a.pos[axis] < b.pos[axis]; });
         if (spawnLevels > 0 && hi - lo > 100000) {
-            std::thread left([&, lo, mid, depth, spawnLevels] { kd_order(ph, idx, lo, mid, depth + 1, spawnLevels - 1); });
-            kd_order(ph, idx, mid + 1, hi, depth + 1, spawnLevels - 1);
+            std::thread left([=] { kd_order(keys, lo, mid, depth + 1, spawnLevels - 1); });
+            kd_order(keys, mid + 1, hi, depth + 1, spawnLevels - 1);
             left.join();
             return;
         }
-        kd_order(ph, idx, lo, mid, depth + 1, 0);
+        kd_order(keys, lo, mid, depth + 1, 0);
         lo = mid + 1;
         depth += 1;
     }
+}
+
+// f(begin, end) over [0, n) on `threads` host threads.
+template <typename F>
+void host_parallel(size_t n, int threads, const F& f)
+{
+    if (threads <= 1 || n < 65536) { f((size_t)0, n); return; }
+    std::vector<std::thread> pool;
+    const size_t chunk = (n + (size_t)threads - 1) / (size_t)threads;
+    for (int t = 0; t < threads; ++t) {
+        const size_t b = (size_t)t * chunk, e = std::min(n, b + chunk);
+        if (b >= e) break;
+        pool.emplace_back([&f, b, e] { f(b, e); });
+    }
+    for (std::thread& t : pool) t.join();
 }
 
 // Bounding cone of the surface normals of every range (stored at the range's middle element): axis and the
@@ -289,24 +311,24 @@ void kd_order(const std::vector<rtgpu_photon>& ph, uint32_t* idx, size_t lo, siz
 // each child cone's axis deviation plus its half angle, a little inflated; ranges whose cone reaches 90 degrees
 // are never culled (limit -2).
 struct Cone { double sx, sy, sz; float ax, ay, az; double alpha; };
-Cone kd_cones(const std::vector<rtgpu_photon>& ph, const uint32_t* idx, std::vector<float4>& out, size_t lo, size_t hi, int spawnLevels)
+Cone kd_cones(const float4* normals, float4* out, size_t lo, size_t hi, int spawnLevels)
 {
     const size_t mid = lo + (hi - lo) / 2;
-    const rtgpu_photon& p = ph[idx[mid]];
+    const float pn[3] = {normals[mid].x, normals[mid].y, normals[mid].z};
     Cone l{}, r{};
     const bool hasL = mid > lo, hasR = hi > mid + 1;
     if (spawnLevels > 0 && hi - lo > 100000) {
-        std::thread t([&] { l = kd_cones(ph, idx, out, lo, mid, spawnLevels - 1); });
-        if (hasR) r = kd_cones(ph, idx, out, mid + 1, hi, spawnLevels - 1);
+        std::thread t([&] { l = kd_cones(normals, out, lo, mid, spawnLevels - 1); });
+        if (hasR) r = kd_cones(normals, out, mid + 1, hi, spawnLevels - 1);
         t.join();
     } else {
-        if (hasL) l = kd_cones(ph, idx, out, lo, mid, 0);
-        if (hasR) r = kd_cones(ph, idx, out, mid + 1, hi, 0);
+        if (hasL) l = kd_cones(normals, out, lo, mid, 0);
+        if (hasR) r = kd_cones(normals, out, mid + 1, hi, 0);
     }
     Cone c{};
-    c.sx = p.normal[0] + (hasL ? l.sx : 0.0) + (hasR ? r.sx : 0.0);
-    c.sy = p.normal[1] + (hasL ? l.sy : 0.0) + (hasR ? r.sy : 0.0);
-    c.sz = p.normal[2] + (hasL ? l.sz : 0.0) + (hasR ? r.sz : 0.0);
+    c.sx = pn[0] + (hasL ? l.sx : 0.0) + (hasR ? r.sx : 0.0);
+    c.sy = pn[1] + (hasL ? l.sy : 0.0) + (hasR ? r.sy : 0.0);
+    c.sz = pn[2] + (hasL ? l.sz : 0.0) + (hasR ? r.sz : 0.0);
     const double len = std::sqrt(c.sx * c.sx + c.sy * c.sy + c.sz * c.sz);
     const double kPi = 3.14159265358979323;
     c.alpha = kPi;
@@ -318,7 +340,7 @@ Cone kd_cones(const std::vector<rtgpu_photon>& ph, const uint32_t* idx, std::vec
             if (!(n > 0) || !std::isfinite(n)) return kPi;   // a degenerate normal: its dot product with anything is 0 or NaN, keep the range
             return std::acos(std::max(-1.0, std::min(1.0, (x * c.ax + y * c.ay + z * c.az) / n)));
         };
-        double a = angle(p.normal[0], p.normal[1], p.normal[2]);
+        double a = angle(pn[0], pn[1], pn[2]);
         if (hasL) a = std::max(a, angle(l.ax, l.ay, l.az) + l.alpha);
         if (hasR) a = std::max(a, angle(r.ax, r.ay, r.az) + r.alpha);
         c.alpha = std::min(kPi, a + 1e-3);
@@ -327,6 +349,19 @@ Cone kd_cones(const std::vector<rtgpu_photon>& ph, const uint32_t* idx, std::vec
     out[2 * mid + 1] = make_float4(c.ax, c.ay, c.az, limit);
     return c;
 }
+
+// RTGPU_PM_STATS=1: phase times of the photon map build on stderr (developer aid)
+struct PhaseClock {
+    const bool on = std::getenv("RTGPU_PM_STATS") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char* what)
+    {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "photon map: %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t).count());
+        t = now;
+    }
+};
 
 struct Dev {
     void* p = nullptr;
@@ -357,17 +392,29 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
     if (ph.size() >= (1ull << 31)) return set_error(RTGPU_ERR_LIMIT, "more than 2^31 photons");
     const size_t n = ph.size();
     if (n) {
-        std::vector<uint32_t> idx(n);
-        for (size_t i = 0; i < n; ++i) idx[i] = (uint32_t)i;
-        kd_order(ph, idx.data(), 0, n, 0, 4);
-        std::vector<float4> pos(2 * n), nrm(n), en(n);   // pos: position and normal cone of the range rooted at the element
-        kd_cones(ph, idx.data(), pos, 0, n, 4);
-        for (size_t i = 0; i < n; ++i) {
-            const rtgpu_photon& p = ph[idx[i]];
-            pos[2 * i] = make_float4(p.pos[0], p.pos[1], p.pos[2], 0.0f);
-            nrm[i] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.0f);
-            en[i] = make_float4(p.energy[0], p.energy[1], p.energy[2], 0.0f);
-        }
+        PhaseClock clock;
+        const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+        std::unique_ptr<KdKey[]> keys(new KdKey[n]);
+        host_parallel(n, threads, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) keys[i] = KdKey{{ph[i].pos[0], ph[i].pos[1], ph[i].pos[2]}, (uint32_t)i};
+        });
+        kd_order(keys.get(), 0, n, 0, 4);
+        clock.lap("median ordering");
+        // pos: position and normal cone of the range rooted at the element.  Not value-initialised: the pages are first
+        // touched by the threads that fill them.
+        std::unique_ptr<float4[]> posMem(new float4[2 * n]), nrmMem(new float4[n]), enMem(new float4[n]);
+        float4 *pos = posMem.get(), *nrm = nrmMem.get(), *en = enMem.get();
+        host_parallel(n, threads, [&](size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {
+                const rtgpu_photon& p = ph[keys[i].index];
+                pos[2 * i] = make_float4(p.pos[0], p.pos[1], p.pos[2], 0.0f);
+                nrm[i] = make_float4(p.normal[0], p.normal[1], p.normal[2], 0.0f);
+                en[i] = make_float4(p.energy[0], p.energy[1], p.energy[2], 0.0f);
+            }
+        });
+        clock.lap("search-order arrays");
+        kd_cones(nrm, pos, 0, n, 4);
+        clock.lap("normal cones");
         void *dp = nullptr, *dn = nullptr, *de = nullptr;
         PH_HIP(hipMalloc(&dp, 2 * n * sizeof(float4)));
         v.kdPos = (const float4*)dp;
@@ -375,9 +422,10 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
         v.kdNormal = (const float4*)dn;
         PH_HIP(hipMalloc(&de, n * sizeof(float4)));
         v.kdEnergy = (const float4*)de;
-        PH_HIP(hipMemcpy(dp, pos.data(), 2 * n * sizeof(float4), hipMemcpyHostToDevice));
-        PH_HIP(hipMemcpy(dn, nrm.data(), n * sizeof(float4), hipMemcpyHostToDevice));
-        PH_HIP(hipMemcpy(de, en.data(), n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dp, pos, 2 * n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(dn, nrm, n * sizeof(float4), hipMemcpyHostToDevice));
+        PH_HIP(hipMemcpy(de, en, n * sizeof(float4), hipMemcpyHostToDevice));
+        clock.lap("upload");
     }
     v.nPhotons = (uint32_t)n;
     v.pmMode = mode;
@@ -417,6 +465,7 @@ int trace_photons(rtgpu_scene& scene, int mode, uint64_t perPoint, uint64_t perA
     PH_HIP(hipMalloc(&dBatches.p, perLaunch * sizeof(EmitBatch)));
     PH_HIP(hipMalloc(&dStarts.p, perLaunch * sizeof(uint32_t)));
     std::vector<rtgpu_photon> host;
+    PhaseClock clock;
     for (size_t b0 = 0; b0 < batches.size(); b0 += perLaunch) {
         const size_t nb = std::min(perLaunch, batches.size() - b0);
         std::vector<uint32_t> starts(nb);
@@ -435,8 +484,39 @@ int trace_photons(rtgpu_scene& scene, int mode, uint64_t perPoint, uint64_t perA
         PH_HIP(hipGetLastError());
         host.resize(nSlots);
         PH_HIP(hipMemcpy(host.data(), dSlots.p, nSlots * sizeof(rtgpu_photon), hipMemcpyDeviceToHost));
-        for (const rtgpu_photon& p : host)
-            if (p.is_caustic != kEmptySlot) scene.photons.push_back(p);
+        clock.lap("trace + slots to host");
+        {   // the filled slots, in slot order, appended to the scene's photons
+            const int threads = (int)std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+            const size_t chunk = (nSlots + (size_t)threads - 1) / (size_t)threads;
+            std::vector<size_t> count((size_t)threads + 1, 0);
+            std::vector<std::thread> pool;
+            for (int t = 0; t < threads; ++t)
+                pool.emplace_back([&, t] {
+                    const size_t b = std::min(nSlots, (size_t)t * chunk), e = std::min(nSlots, b + chunk);
+                    size_t c = 0;
+                    for (size_t i = b; i < e; ++i) c += host[i].is_caustic != kEmptySlot;
+                    count[(size_t)t + 1] = c;
+                });
+            for (std::thread& t : pool) t.join();
+            pool.clear();
+            for (int t = 0; t < threads; ++t) count[(size_t)t + 1] += count[(size_t)t];
+            const size_t base = scene.photons.size();
+            if (b0 == 0 && batches.size() > perLaunch) {
+                // the first launch tells how full the slots get: room for the launches to come (one growth instead of several)
+                const double perBatch = (double)count[(size_t)threads] / (double)nb;
+                scene.photons.reserve((size_t)(perBatch * 1.1 * (double)batches.size()) + 1024);
+            }
+            scene.photons.resize(base + count[(size_t)threads]);
+            for (int t = 0; t < threads; ++t)
+                pool.emplace_back([&, t] {
+                    const size_t b = std::min(nSlots, (size_t)t * chunk), e = std::min(nSlots, b + chunk);
+                    rtgpu_photon* out = scene.photons.data() + base + count[(size_t)t];
+                    for (size_t i = b; i < e; ++i)
+                        if (host[i].is_caustic != kEmptySlot) *out++ = host[i];
+                });
+            for (std::thread& t : pool) t.join();
+        }
+        clock.lap("keep filled slots");
     }
     return RTGPU_OK;
 }
