@@ -410,10 +410,9 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
         if (nodeStep) {
             // ---- inner node of the top-level tree or of a mesh tree ------------------------------------
             if (busy && cur >= 0) {
-                tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
-                __builtin_amdgcn_sched_barrier(0);   // as in trace_wave_steal
                 const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
+                tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
                 if (COUNT) wb += 2;
                 float t0a, t0b;
                 const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
