@@ -29,11 +29,15 @@ __device__ inline bool gather_photons(const SceneView& sv, F3 q, F3 dir, uint32_
     // first, then the node's own photon, then the other child if the split plane is within the search radius -- near
     // photons fill the list first and the radius is small before the far sides are looked at.  A stack entry is the
     // far range of a node; popping it first tests that node's photon (its near subtree is finished by then).
-    constexpr uint32_t kNoParent = 1u << 30, kRightSide = 1u << 31;
-    struct Entry { uint32_t lo, hi; float plane2, d2; uint32_t dk; };   // d2: squared distance of the node's photon; dk: depth | flags
-    Entry stack[40];
+    // A stack entry is 16 bytes (the stacks of a wave's lanes are what the kernel moves most through memory): lo and hi
+    // are below 2^31 and carry depth % 3 in their top bits, the two squared distances are not negative and carry the
+    // flags "no parent to test" and "the range lies right of its parent" in their sign bits.  The tree is at most 31
+    // levels deep, so 32 entries are enough.
+    constexpr uint32_t kTop = 0x80000000u;
+    constexpr int kStack = 32;
+    uint4 stack[kStack];
     int sp = 0;
-    if (sv.nPhotons) { stack[0] = Entry{0u, sv.nPhotons, 0.0f, 0.0f, kNoParent}; sp = 1; }
+    if (sv.nPhotons) { stack[0] = make_uint4(0u, sv.nPhotons, kTop, 0u); sp = 1; }   // depth 0, no parent
     const float qa[3] = {q.x, q.y, q.z};
     const float dirLen = norm3(dir);
     // a photon at squared distance d2: the filter of DiffuseMaterial.cpp:66-68, then KDTreeNode::insert (KDTree.h:225-245)
@@ -63,11 +67,13 @@ __device__ inline bool gather_photons(const SceneView& sv, F3 q, F3 dir, uint32_
     uint32_t visited = 0;
     while (sp > 0) {
         if (visited > budget) return false;
-        const Entry e = stack[--sp];
-        if (!(e.dk & kNoParent)) offer((e.dk & kRightSide) ? e.lo - 1u : e.hi, e.d2);   // the node whose far range this is
-        if (e.hi <= e.lo || e.plane2 > r2) continue;   // distanceToSplitPlane <= searchRadius, KDTree.h:153
-        uint32_t lo = e.lo, hi = e.hi, depth = e.dk & 0xFFu;
-        while (hi > lo && sp < 40) {                   // down the query's side, leaving the far ranges behind
+        const uint4 e = stack[--sp];
+        uint32_t lo = e.x & ~kTop, hi = e.y & ~kTop;
+        uint32_t d3 = (e.x >> 31) | ((e.y >> 31) << 1);   // depth % 3
+        const float plane2 = __uint_as_float(e.z & ~kTop);
+        if (!(e.z & kTop)) offer((e.w & kTop) ? lo - 1u : hi, __uint_as_float(e.w & ~kTop));   // the node whose far range this is
+        if (hi <= lo || plane2 > r2) continue;   // distanceToSplitPlane <= searchRadius, KDTree.h:153
+        while (hi > lo && sp < kStack) {               // down the query's side, leaving the far ranges behind
             const uint32_t mid = lo + (hi - lo) / 2u;
             ++visited;
             const float4 p = sv.kdPos[2u * mid], cone = sv.kdPos[2u * mid + 1u];
@@ -76,13 +82,15 @@ __device__ inline bool gather_photons(const SceneView& sv, F3 q, F3 dir, uint32_
             const F3 diff = f3(p.x, p.y, p.z) - q;
             const float d2 = dot3(diff, diff);
             if (hi - lo == 1u) { offer(mid, d2); break; }   // a leaf: nothing below it
-            const uint32_t axis = (depth + 1u) % 3u;   // KDTreeBuilder::buildNode: the axis after the parent's, x before the root
+            const uint32_t axis = d3 == 2u ? 0u : d3 + 1u;   // KDTreeBuilder::buildNode: the axis after the parent's, x before the root
             const float pa = axis == 0u ? p.x : (axis == 1u ? p.y : p.z);
             const float delta = qa[axis] - pa;
             const bool right = pa < qa[axis];          // targetContainingChildIdx, KDTree.h:122
-            depth += 1u;
-            if (right) { stack[sp++] = Entry{lo, mid, delta * delta, d2, depth}; lo = mid + 1u; }
-            else { stack[sp++] = Entry{mid + 1u, hi, delta * delta, d2, depth | kRightSide}; hi = mid; }
+            d3 = axis;                                 // (depth + 1) % 3
+            const uint32_t dLo = (d3 & 1u) << 31, dHi = (d3 >> 1) << 31;
+            const uint32_t planeBits = __float_as_uint(delta * delta), d2Bits = __float_as_uint(d2);
+            if (right) { stack[sp++] = make_uint4(lo | dLo, mid | dHi, planeBits, d2Bits); lo = mid + 1u; }
+            else { stack[sp++] = make_uint4((mid + 1u) | dLo, hi | dHi, planeBits, d2Bits | kTop); hi = mid; }
         }
     }
     count = (uint32_t)found;
