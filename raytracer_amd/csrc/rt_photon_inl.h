@@ -118,7 +118,10 @@ __device__ inline bool gather_photons(const SceneView& sv, F3 q, F3 dir, uint32_
 // by the whole wave for one candidate at a time.  Ranges are cut off by the same two tests (split plane against the
 // current radius, cone of normals against the filter), so the photons found are the k nearest that pass the
 // filter -- the set gather_photons() finds, ties in distance aside.
-constexpr int kWaveStack = 2048;       // entries the stack may hold while 64 lanes pop together
+#ifndef RT_WAVE_STACK
+#define RT_WAVE_STACK 448
+#endif
+constexpr int kWaveStack = RT_WAVE_STACK;      // entries the stack may hold while 64 lanes pop together
 constexpr int kWaveStackSlack = 64;    // room for the one-lane descent that runs when the stack is that full
 
 struct GatherWaveLds {
