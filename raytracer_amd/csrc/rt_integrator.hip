@@ -172,10 +172,10 @@ __device__ __forceinline__ void queue_push1(uint32_t* q, uint32_t* c, bool pred,
 }
 
 // ---- primary ---------------------------------------------------------------------------------
-template <bool INSTANCED>
+template <int MODE>
 __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
 {
-    __shared__ typename TraceLds<INSTANCED>::type lds;
+    __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint32_t s0 = blockIdx.x * 64u + lane;
@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     tile_pixel(st, batch.pixelStart + pl, x, y);
     F3 o, d;
     camera_ray(cam, st, x, y, (int)i, o, d);
-    const TraceResult r = wave_closest<INSTANCED>(sv, has, o, d, lds, lane);
+    const TraceResult r = wave_closest<MODE>(sv, has, o, d, lds, lane);
     if (!has) return;
     const bool hit = r.inst != kInvalid;
 
@@ -751,9 +751,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
 // ---- shadow / connect and extend ------------------------------------------------------------------
 // Both run after a shade pass and are independent of each other, so one launch carries both: the
 // first workgroups trace the extension rays (closest hit), the rest the shadow rays (any hit).
-template <bool INSTANCED>
+template <int MODE>
 __device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& pool, uint32_t block, uint32_t n,
-                                             typename TraceLds<INSTANCED>::type& lds, int lane)
+                                             typename TraceLds<MODE>::type& lds, int lane)
 {
     const uint32_t q = block * 64u + lane;
     const bool has = q < n;
@@ -762,7 +762,7 @@ __device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& po
     // a glass vertex asks whether the light along the direction it did not take is visible
     const bool sticky = sv.hasGlass && (__float_as_uint(rb.w) & ST_GLASS_STICKY) != 0;
     if (sticky) { ra = pool.glassA[p]; rb = pool.glassB[p]; }
-    const bool occluded = wave_any<INSTANCED>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), ra.w, lds, lane);
+    const bool occluded = wave_any<MODE>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), ra.w, lds, lane);
     if (!has) return;
     if (sticky) {
         if (occluded) pool.glassB[p] = f4(rb.x, rb.y, rb.z, __uint_as_float(kInvalid));
@@ -771,28 +771,28 @@ __device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& po
     }
 }
 
-template <bool INSTANCED>
+template <int MODE>
 __device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& pool, const uint32_t* __restrict__ queue, uint32_t block,
-                                             uint32_t n, typename TraceLds<INSTANCED>::type& lds, int lane)
+                                             uint32_t n, typename TraceLds<MODE>::type& lds, int lane)
 {
     const uint32_t q = block * 64u + lane;
     const bool has = q < n;
     const uint32_t p = queue[has ? q : 0u];
     const float4 ra = pool.rayA[p], rb = pool.rayB[p];
-    const TraceResult r = wave_closest<INSTANCED>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), lds, lane);
+    const TraceResult r = wave_closest<MODE>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), lds, lane);
     if (!has) return;
     pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
-    if (INSTANCED) pool.hitInst[p] = r.inst;
+    if (MODE != kTraceSingle) pool.hitInst[p] = r.inst;
 }
 
-template <bool INSTANCED>
+template <int MODE>
 __global__ __launch_bounds__(64) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, uint32_t nExt, uint32_t nShadow)
 {
-    __shared__ typename TraceLds<INSTANCED>::type lds;
+    __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
     const uint32_t extBlocks = (nExt + 63u) / 64u;
-    if (blockIdx.x < extBlocks) extend_block<INSTANCED>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
-    else shadow_block<INSTANCED>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
+    if (blockIdx.x < extBlocks) extend_block<MODE>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
+    else shadow_block<MODE>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
 }
 
 // ---- photon gather ----------------------------------------------------------------------------------
@@ -1011,7 +1011,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
         const hipStream_t ls = ln.stream;
         uint32_t* h = ln.hostCounters;
-        const bool single = sv.singleMesh != 0;
+        const int mode = trace_mode(sv);
         const bool gatherStats = std::getenv("RTGPU_GATHER_STATS") != nullptr;
         const uint32_t tailCap = std::getenv("RTGPU_GATHER_TAIL_BLOCKS") ? (uint32_t)std::atoi(std::getenv("RTGPU_GATHER_TAIL_BLOCKS")) : 16384u;
         const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode != RTGPU_PM_NONE;
@@ -1023,8 +1023,9 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
             const uint32_t nS = batch.nPixels * G;
             const uint32_t nP = nS * M;
             LN_TRY(hipMemsetAsync(pool.counters, 0, kPoolCounters * sizeof(uint32_t), ls));
-            if (single) hipLaunchKernelGGL((primary_kernel<false>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
-            else hipLaunchKernelGGL((primary_kernel<true>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
+            if (mode == kTraceSingle) hipLaunchKernelGGL((primary_kernel<kTraceSingle>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
+            else if (mode == kTraceInstances) hipLaunchKernelGGL((primary_kernel<kTraceInstances>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
+            else hipLaunchKernelGGL((primary_kernel<kTraceLanes>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
             ln.primary += nS;
             uint32_t nActive = nP;   // the first shade pass runs over every path of the batch
             uint32_t* qIn = pool.qA;
@@ -1055,8 +1056,9 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                 }
                 if (nShadow || nExt) {
                     const uint32_t blocks = (nExt + 63) / 64 + (nShadow + 63) / 64;
-                    if (single) hipLaunchKernelGGL((trace_stage_kernel<false>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
-                    else hipLaunchKernelGGL((trace_stage_kernel<true>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
+                    if (mode == kTraceSingle) hipLaunchKernelGGL((trace_stage_kernel<kTraceSingle>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
+                    else if (mode == kTraceInstances) hipLaunchKernelGGL((trace_stage_kernel<kTraceInstances>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
+                    else hipLaunchKernelGGL((trace_stage_kernel<kTraceLanes>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
                 }
                 ln.extension += nExt - nRepeated;
                 ln.shadow += nShadow;

@@ -134,12 +134,12 @@ __device__ void interact_photon(const SceneView& sv, uint32_t mi, uint32_t inst,
 }
 
 // One lane per ray of the launch; batchStart[b] is the launch-local index of batch b's first ray.
-template <bool INSTANCED>
+template <int MODE>
 __global__ __launch_bounds__(64) void photon_trace_kernel(SceneView sv, const EmitBatch* __restrict__ batches, const uint32_t* __restrict__ batchStart,
                                                           uint32_t nBatches, uint32_t nRays, int mode, double perPoint, float perArea, uint32_t seed,
                                                           rtgpu_photon* __restrict__ slots)
 {
-    __shared__ typename TraceLds<INSTANCED>::type lds;
+    __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
     const uint32_t r = blockIdx.x * 64u + lane;
     bool alive = r < nRays;
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(64) void photon_trace_kernel(SceneView sv, const Em
     bool hasPassedSpecular = false;
     for (int v = 0; v < kMaxPhotonDepth; ++v) {   // PhotonDriver::trace, :12-58
         if (__ballot(alive) == 0ull) break;
-        const TraceResult hr = wave_closest<INSTANCED>(sv, alive, o, d, lds, lane);
+        const TraceResult hr = wave_closest<MODE>(sv, alive, o, d, lds, lane);
         if (!alive) continue;
         if (hr.inst == kInvalid) { alive = false; continue; }
         const DevInstance& in = sv.inst[hr.inst];
@@ -475,11 +475,16 @@ int trace_photons(rtgpu_scene& scene, int mode, uint64_t perPoint, uint64_t perA
         PH_HIP(hipMemcpy(dBatches.p, batches.data() + b0, nb * sizeof(EmitBatch), hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(dStarts.p, starts.data(), nb * sizeof(uint32_t), hipMemcpyHostToDevice));
         hipLaunchKernelGGL(fill_empty_kernel, dim3((unsigned)((nSlots + 255) / 256)), dim3(256), 0, nullptr, (rtgpu_photon*)dSlots.p, nSlots);
-        if (sv.singleMesh)
-            hipLaunchKernelGGL((photon_trace_kernel<false>), dim3((nRays + 63) / 64), dim3(64), 0, nullptr, sv, (const EmitBatch*)dBatches.p,
+        const dim3 grid((nRays + 63) / 64), block(64);
+        const int traceMode = trace_mode(sv);
+        if (traceMode == kTraceSingle)
+            hipLaunchKernelGGL((photon_trace_kernel<kTraceSingle>), grid, block, 0, nullptr, sv, (const EmitBatch*)dBatches.p,
+                               (const uint32_t*)dStarts.p, (uint32_t)nb, nRays, mode, (double)perPoint, (float)perArea, seed, (rtgpu_photon*)dSlots.p);
+        else if (traceMode == kTraceInstances)
+            hipLaunchKernelGGL((photon_trace_kernel<kTraceInstances>), grid, block, 0, nullptr, sv, (const EmitBatch*)dBatches.p,
                                (const uint32_t*)dStarts.p, (uint32_t)nb, nRays, mode, (double)perPoint, (float)perArea, seed, (rtgpu_photon*)dSlots.p);
         else
-            hipLaunchKernelGGL((photon_trace_kernel<true>), dim3((nRays + 63) / 64), dim3(64), 0, nullptr, sv, (const EmitBatch*)dBatches.p,
+            hipLaunchKernelGGL((photon_trace_kernel<kTraceLanes>), grid, block, 0, nullptr, sv, (const EmitBatch*)dBatches.p,
                                (const uint32_t*)dStarts.p, (uint32_t)nb, nRays, mode, (double)perPoint, (float)perArea, seed, (rtgpu_photon*)dSlots.p);
         PH_HIP(hipGetLastError());
         host.resize(nSlots);

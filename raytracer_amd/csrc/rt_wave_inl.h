@@ -8,46 +8,55 @@
 
 namespace rt {
 
-// Per-wave LDS of a traversal kernel: the work-stealing state for single-mesh scenes, the plain
-// per-lane stack otherwise.
-template <bool INSTANCED>
+// How a kernel finds hits: the wave-cooperative walk over one mesh, the wave-cooperative walk over mesh instances
+// (what a file of many objects gives), or the per-lane walks (scenes with analytic spheres, whose top-level tree is the
+// reference's own, and scenes whose tie-break keys do not fit 32 bits).  A template parameter, so that every kernel
+// variant only carries the registers and the LDS of its own walk.
+enum TraceMode : int { kTraceSingle = 0, kTraceInstances = 1, kTraceLanes = 2 };
+inline int trace_mode(const SceneView& sv) { return sv.singleMesh ? kTraceSingle : (sv.coopInstanced ? kTraceInstances : kTraceLanes); }
+
+// Per-wave LDS of a traversal kernel.
+template <int MODE>
 struct TraceLds {
-    union type {   // per-lane stack (reference-order walk, scenes whose keys do not fit) or the cooperative state
-        int stack[kLdsStack][64];
-        StealLdsInst<false> coop;
-    };
+    struct type { int stack[kLdsStack][64]; };   // per-lane stacks
 };
 template <>
-struct TraceLds<false> {
+struct TraceLds<kTraceSingle> {
     using type = StealLds<false>;
+};
+template <>
+struct TraceLds<kTraceInstances> {
+    using type = StealLdsInst<false>;
 };
 
 // Closest hit for the wave's rays (every lane calls; lanes without a ray pass has = false).
-template <bool INSTANCED>
-__device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool has, F3 o, F3 d, typename TraceLds<INSTANCED>::type& lds, int lane)
+template <int MODE>
+__device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool has, F3 o, F3 d, typename TraceLds<MODE>::type& lds, int lane)
 {
     uint32_t nb = 0, nt = 0;
-    if constexpr (!INSTANCED) {
+    if constexpr (MODE == kTraceSingle) {
         TraceResult r = trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
         if (r.slot != kInvalid) hit_barycentrics(sv, r.slot, o, d, r.beta, r.gamma);
         return r;
+    } else if constexpr (MODE == kTraceInstances) {
+        return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     } else {
         TraceResult r;
         r.t = INFINITY; r.slot = kInvalid; r.inst = kInvalid; r.beta = 0.0f; r.gamma = 0.0f;
-        if (sv.coopInstanced) return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
         if (!has) return r;
         if (sv.refTop) return trace_ray_reftop_closest<false>(sv, o, d, lds.stack, lane, nb, nt);
         return trace_ray<true, false, false>(sv, o, d, INFINITY, lds.stack, lane, nb, nt);
     }
 }
-template <bool INSTANCED>
-__device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3 d, float tmax, typename TraceLds<INSTANCED>::type& lds, int lane)
+template <int MODE>
+__device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3 d, float tmax, typename TraceLds<MODE>::type& lds, int lane)
 {
     uint32_t nb = 0, nt = 0;
-    if constexpr (!INSTANCED) {
+    if constexpr (MODE == kTraceSingle) {
         return trace_wave_steal<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
+    } else if constexpr (MODE == kTraceInstances) {
+        return trace_wave_steal_inst<true, false>(sv, has, o, d, tmax, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
     } else {
-        if (sv.coopInstanced) return trace_wave_steal_inst<true, false>(sv, has, o, d, tmax, lds.coop, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct).inst != kInvalid;
         if (!has) return false;
         if (sv.refTop) return trace_ray_reftop_any(sv, o, d, tmax, lds.stack, lane);
         return trace_ray<true, true, false>(sv, o, d, tmax, lds.stack, lane, nb, nt).inst != kInvalid;
