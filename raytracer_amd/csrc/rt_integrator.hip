@@ -786,7 +786,7 @@ __device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& po
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, uint32_t nExt, uint32_t nShadow)
+__global__ __launch_bounds__(64, MODE == kTraceInstances ? 6 : 1) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, uint32_t nExt, uint32_t nShadow)
 {
     __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
