@@ -221,7 +221,7 @@ int main(int argc, char** argv)
                 if (loadPm) {
                     std::printf("Loading photon map...\n");
                     const std::vector<rtgpu_photon> photons = loadPhotons(photonMapFilePath.string());
-                    rtgpu::check(rtgpu_scene_set_photons(scene.mutableHandle(), photons.data(), photons.size(), pmMode, pmDepth));
+                    scene.setPhotons(photons, (rtgpu_photon_map_mode)pmMode, pmDepth);
                     std::printf("Loaded %llu photons\n", (unsigned long long)photons.size());
                 } else {
                     std::printf("Building photon map...\n");
@@ -230,11 +230,7 @@ int main(int argc, char** argv)
                 }
                 if (savePm) {
                     std::printf("Saving photon map...\n");
-                    uint64_t n = 0;
-                    rtgpu::check(rtgpu_scene_get_photons(scene.handle(), nullptr, 0, &n));
-                    std::vector<rtgpu_photon> photons(n);
-                    rtgpu::check(rtgpu_scene_get_photons(scene.handle(), photons.data(), n, &n));
-                    savePhotons(photons, photonMapFilePath.string());
+                    savePhotons(scene.photons(), photonMapFilePath.string());
                 }
             }
             std::printf("Rendering...\n");

@@ -23,6 +23,7 @@
 #include <optional>
 #include <stdexcept>
 #include <string>
+#include <vector>
 
 #include "rtgpu.h"
 
@@ -69,6 +70,21 @@ public:
         uint64_t n = 0;
         check(rtgpu_scene_build_photon_map(scene_, mode, depth, raysPerPointLight, raysPerAreaLight, seed, &n));
         return n;
+    }
+
+    // The photons of the map (PhotonMap::serialize / deserialize as memory transfers, exe/Raytracer.cpp:299-318) and
+    // Scene::setPhotonMap + setPhotonMapMode + setPhotonMapDepth with photons from elsewhere.
+    std::vector<rtgpu_photon> photons() const
+    {
+        uint64_t n = 0;
+        check(rtgpu_scene_get_photons(scene_, nullptr, 0, &n));
+        std::vector<rtgpu_photon> out(n);
+        check(rtgpu_scene_get_photons(scene_, out.data(), n, &n));
+        return out;
+    }
+    void setPhotons(const std::vector<rtgpu_photon>& photons, rtgpu_photon_map_mode mode, int depth)
+    {
+        check(rtgpu_scene_set_photons(scene_, photons.data(), photons.size(), mode, depth));
     }
 
     // Scene::traceRay (scene/renderable/Scene.cpp:14-17)
