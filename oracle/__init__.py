@@ -182,3 +182,43 @@ def generate_primary(cam, st, sample_index=0):
     d = np.empty((n, 3), dtype=np.float32)
     lib().orc_generate_primary(C.byref(cam), C.byref(st), int(sample_index), _fp(o), _fp(d))
     return o, d
+
+
+def kd_nearest_explicit(points, child0, child1, axis, target, count, max_radius=None):
+    """KDTree::getElementsNearestTo on a hand-built tree (node i holds point i, root = node 0): returns
+    (found, max_dist, point indices nearest first with -1 for empty entries)."""
+    L = lib()
+    L.orc_kd_nearest_explicit.restype = C.c_uint32
+    L.orc_kd_nearest_explicit.argtypes = [abi.c_float_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32, abi.c_float_p,
+                                          C.c_uint32, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
+    p = _f32(points).reshape(-1, 3)
+    c0, c1, ax = (np.ascontiguousarray(a, dtype=np.int32) for a in (child0, child1, axis))
+    t = _f32(target).reshape(3)
+    res = np.full(count, -1, dtype=np.int64)
+    md = C.c_float()
+    r = np.finfo(np.float32).max if max_radius is None else max_radius
+    found = L.orc_kd_nearest_explicit(_fp(p), c0.ctypes.data, c1.ctypes.data, ax.ctypes.data, len(p), _fp(t), int(count),
+                                      float(r), res.ctypes.data, C.byref(md))
+    return int(found), np.float32(md.value), res
+
+
+def kd_nearest_built(points, target, count, max_radius=None):
+    """The same query on the tree KDTreeBuilder::build makes over `points`."""
+    L = lib()
+    L.orc_kd_nearest_built.restype = C.c_uint32
+    L.orc_kd_nearest_built.argtypes = [abi.c_float_p, C.c_uint32, abi.c_float_p, C.c_uint32, C.c_float, C.c_void_p, C.POINTER(C.c_float)]
+    p = _f32(points).reshape(-1, 3)
+    t = _f32(target).reshape(3)
+    res = np.full(count, -1, dtype=np.int64)
+    md = C.c_float()
+    r = np.finfo(np.float32).max if max_radius is None else max_radius
+    found = L.orc_kd_nearest_built(_fp(p), len(p), _fp(t), int(count), float(r), res.ctypes.data, C.byref(md))
+    return int(found), np.float32(md.value), res
+
+
+def aabb_corners(lo, hi):
+    L = lib()
+    L.orc_aabb_corners.argtypes = [abi.c_float_p, abi.c_float_p, abi.c_float_p]
+    out = np.empty((8, 3), dtype=np.float32)
+    L.orc_aabb_corners(_fp(_f32(lo).reshape(3)), _fp(_f32(hi).reshape(3)), _fp(out))
+    return out

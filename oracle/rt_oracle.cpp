@@ -211,10 +211,18 @@ inline double aabb_area(const AABB& a)
     return 2.0 * (x * y + z * y + x * z);
 }
 // AABB::getAABBOfTransformed, shape/AABB.cpp:19-46
+// Box::getCorners, shape/Box.cpp (the eight corners AABB::getAABBOfTransformed maps, shape/AABB.cpp:33-46)
+inline void aabb_corners(const AABB& a, V3 c[8])
+{
+    const V3 k[8] = {a.s, V3{a.s.x, a.s.y, a.e.z}, V3{a.s.x, a.e.y, a.s.z}, V3{a.e.x, a.s.y, a.s.z},
+                     V3{a.s.x, a.e.y, a.e.z}, V3{a.e.x, a.s.y, a.e.z}, V3{a.e.x, a.e.y, a.s.z}, a.e};
+    for (int i = 0; i < 8; ++i) c[i] = k[i];
+}
+
 inline AABB aabb_of_transformed(const AABB& a, const double* M)
 {
-    V3 c[8] = {a.s, V3{a.s.x, a.s.y, a.e.z}, V3{a.s.x, a.e.y, a.s.z}, V3{a.e.x, a.s.y, a.s.z},
-               V3{a.s.x, a.e.y, a.e.z}, V3{a.e.x, a.s.y, a.e.z}, V3{a.e.x, a.e.y, a.s.z}, a.e};
+    V3 c[8];
+    aabb_corners(a, c);
     AABB r;
     r.s = V3{INFINITY, INFINITY, INFINITY};
     r.e = V3{-INFINITY, -INFINITY, -INFINITY};
@@ -2249,6 +2257,64 @@ void orc_aabb_merge(const float lo0[3], const float hi0[3], const float lo1[3], 
     out_hi[0] = r.e.x; out_hi[1] = r.e.y; out_hi[2] = r.e.z;
 }
 double orc_aabb_area(const float lo[3], const float hi[3]) { return aabb_area(AABB{mk(lo), mk(hi)}); }
+void orc_aabb_corners(const float lo[3], const float hi[3], float out[24])
+{
+    V3 c[8];
+    aabb_corners(AABB{mk(lo), mk(hi)}, c);
+    for (int i = 0; i < 8; ++i) { out[3 * i] = c[i].x; out[3 * i + 1] = c[i].y; out[3 * i + 2] = c[i].z; }
+}
+
+// KDTree::getElementsNearestTo (photonmapping/KDTree.h:380-409) on a tree given node by node, the way the reference's
+// tests build theirs (test/KDTree.cpp:20-163: KDTreeNode::setChild / setAxis): node i holds point i, children are node
+// indices or -1, the root is node 0.  Every element passes the filter (the three-argument overload, KDTree.h:405-409).
+uint32_t orc_kd_nearest_explicit(const float* points, const int32_t* child0, const int32_t* child1, const int32_t* axis,
+                                 uint32_t n_nodes, const float target[3], uint32_t count, float max_radius,
+                                 int64_t* out_results, float* out_max_dist)
+{
+    orc_scene S;
+    S.photons.resize(n_nodes);
+    S.kd.resize(n_nodes);
+    for (uint32_t i = 0; i < n_nodes; ++i) {
+        rtgpu_photon ph{};
+        std::memcpy(ph.pos, points + 3 * (size_t)i, 12);
+        S.photons[i] = ph;   // normal 0: dot(dir, normal) >= 0 holds for every direction
+        S.kd[i] = orc_scene::KdNode{{child0[i], child1[i]}, i, axis[i]};
+    }
+    S.kdRoot = n_nodes ? 0 : -1;
+    float searchRadius = max_radius;
+    unsigned found = 0;
+    Gather g{S, mk(target), V3{0, 0, 0}, count, std::vector<int64_t>(count, -1)};
+    if (S.kdRoot >= 0) {
+        const float big = std::numeric_limits<float>::max();
+        g.visit(S.kdRoot, true, searchRadius, found, V3{-big, -big, -big}, V3{big, big, big});
+    }
+    for (uint32_t i = 0; i < count; ++i) out_results[i] = g.results[i];
+    *out_max_dist = searchRadius;
+    return found;
+}
+// KDTreeBuilder::build over `n` points (photonmapping/KDTreeBuilder.h:258-276), then the same query: results are point indices.
+uint32_t orc_kd_nearest_built(const float* points, uint32_t n, const float target[3], uint32_t count, float max_radius,
+                              int64_t* out_results, float* out_max_dist)
+{
+    orc_scene S;
+    S.photons.resize(n);
+    for (uint32_t i = 0; i < n; ++i) {
+        rtgpu_photon ph{};
+        std::memcpy(ph.pos, points + 3 * (size_t)i, 12);
+        S.photons[i] = ph;
+    }
+    kd_build_all(S);
+    float searchRadius = max_radius;
+    unsigned found = 0;
+    Gather g{S, mk(target), V3{0, 0, 0}, count, std::vector<int64_t>(count, -1)};
+    if (S.kdRoot >= 0) {
+        const float big = std::numeric_limits<float>::max();
+        g.visit(S.kdRoot, true, searchRadius, found, V3{-big, -big, -big}, V3{big, big, big});
+    }
+    for (uint32_t i = 0; i < count; ++i) out_results[i] = g.results[i];
+    *out_max_dist = searchRadius;
+    return found;
+}
 
 // Transformation::rotateQuaternion, math/Transformation.cpp:104-117 (inverse = transpose for a rotation)
 void orc_rotate_quaternion(double i, double j, double k, double r, double out_m[16], double out_inv[16])

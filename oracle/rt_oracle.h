@@ -71,6 +71,15 @@ float orc_fresnel_mix_factor(const float normal[3], const float dir[3], float io
 void orc_aabb_of_transformed(const float lo[3], const float hi[3], const double m[16], float out_lo[3], float out_hi[3]);
 void orc_aabb_merge(const float lo0[3], const float hi0[3], const float lo1[3], const float hi1[3], float out_lo[3], float out_hi[3]);
 double orc_aabb_area(const float lo[3], const float hi[3]);
+void orc_aabb_corners(const float lo[3], const float hi[3], float out[24]); /* Box::getCorners, test/Box.cpp:7-16 */
+/* KDTree::getElementsNearestTo on a tree given node by node (node i holds point i; children = node indices or -1; root =
+ * node 0), as the reference's tests build theirs (test/KDTree.cpp:20-163), and on the tree KDTreeBuilder::build makes.
+ * out_results: `count` point indices nearest first, -1 = empty.  Returns the number found. */
+uint32_t orc_kd_nearest_explicit(const float* points, const int32_t* child0, const int32_t* child1, const int32_t* axis,
+                                 uint32_t n_nodes, const float target[3], uint32_t count, float max_radius,
+                                 int64_t* out_results, float* out_max_dist);
+uint32_t orc_kd_nearest_built(const float* points, uint32_t n, const float target[3], uint32_t count, float max_radius,
+                              int64_t* out_results, float* out_max_dist);
 void orc_rotate_quaternion(double i, double j, double k, double r, double out_m[16], double out_inv[16]);
 void orc_transform_vector(const double m[16], const float v[3], float out[3]);
 void orc_transform_point(const double m[16], const float p[3], float out[3]);

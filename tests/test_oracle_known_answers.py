@@ -75,6 +75,55 @@ def test_quaternion_rotation(quat, vec, expect):
             assert float_eq(got, want), (got, want)
 
 
+def test_box_corners_and_aabb():
+    """raytracer/test/Box.cpp:7-24: the eight corners of Box(-1,-2,-3 .. 4,5,6) in any order; its AABB is itself
+    (an identity transform maps the box onto itself)."""
+    got = {tuple(c) for c in oracle.aabb_corners((-1, -2, -3), (4, 5, 6)).tolist()}
+    want = {(-1, -2, -3), (-1, -2, 6), (-1, 5, -3), (4, -2, -3), (-1, 5, 6), (4, -2, 6), (4, 5, -3), (4, 5, 6)}
+    assert got == want and len(got) == 8
+    L = oracle.lib()
+    lo, hi = f3(0, 0, 0), f3(0, 0, 0)
+    m = (C.c_double * 16)(*np.eye(4).reshape(-1).tolist())
+    L.orc_aabb_of_transformed(f3(-1, -2, -3), f3(4, 5, 6), m, lo, hi)
+    assert list(lo) == [-1, -2, -3] and list(hi) == [4, 5, 6]
+
+
+@pytest.mark.parametrize("case", __import__("kdtree_vectors").CASES, ids=lambda c: c[0])
+def test_photon_tree_nearest_neighbours(case):
+    """raytracer/test/KDTree.cpp:20-163 and test/KDTreeBuilder.cpp:20-38 against the oracle's restatement of
+    KDTreeNode::getElementsNearestTo / insert: count, result order, and the returned radius."""
+    name, pts, c0, c1, ax, target, count, order, named = case
+    found, max_dist, res = oracle.kd_nearest_explicit(pts, c0, c1, ax, target, count)
+    assert found == count                                    # ASSERT_EQ(nbPhotonsFound, ...)
+    assert res.tolist() == order                             # ASSERT_EQ(resultsList[i], node...)
+    p, t = np.asarray(pts, np.float32), np.asarray(target, np.float32)
+    dist = lambda i: np.sqrt(((p[i] - t) ** 2).sum(dtype=np.float32))
+    # what the reference's source returns: the distance of the last entry of the (full) result list
+    assert float_eq(max_dist, dist(order[-1]))
+    if named is not None and count == 1:
+        assert float_eq(max_dist, dist(named))               # ASSERT_FLOAT_EQ(maxDist, ...) holds as written
+    if named is not None and count == 2:
+        # the test names the nearest result; KDTreeNode::insert returns the farthest (see kdtree_vectors.py)
+        assert named == order[0] and max_dist > dist(named)
+    # the same points through KDTreeBuilder::build give the same neighbours in the same order
+    found_b, max_dist_b, res_b = oracle.kd_nearest_built(pts, target, count)
+    assert (found_b, res_b.tolist()) == (found, order) and max_dist_b == max_dist
+
+
+def test_photon_tree_radius_and_fewer_points_than_asked_for():
+    """KDTreeNode::insert (photonmapping/KDTree.h:230-250): while the list still has an empty entry the radius stays at
+    FLT_MAX -- so a starting radius (getElementsNearestTo's maxRadius, :380-403) only holds until the first point is
+    accepted: with radius 2 the point at distance 1 is taken, the radius jumps to FLT_MAX and the point at distance 4
+    is taken as well.  A radius that excludes every point stays as given."""
+    name, pts, c0, c1, ax, target, count, order, _ = __import__("kdtree_vectors").CASES[0]
+    found, max_dist, res = oracle.kd_nearest_explicit(pts, c0, c1, ax, target, 5)
+    assert found == 3 and res.tolist() == [1, 0, 2, -1, -1] and max_dist == np.finfo(np.float32).max
+    found, max_dist, res = oracle.kd_nearest_explicit(pts, c0, c1, ax, target, 2, max_radius=2.0)
+    assert found == 2 and res.tolist() == [1, 0] and max_dist == np.float32(4.0)
+    found, max_dist, res = oracle.kd_nearest_explicit(pts, c0, c1, ax, target, 2, max_radius=0.5)
+    assert found == 0 and res.tolist() == [-1, -1] and max_dist == np.float32(0.5)
+
+
 def test_bvh_two_spheres():
     """raytracer/test/BVH.cpp:18-49: unit spheres at x = -2 / +2, rays from the origin along -x / +x
     hit sphere 1 / sphere 2 (t = 1)."""

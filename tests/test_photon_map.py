@@ -239,3 +239,39 @@ def test_gpu_render_in_caustics_mode_matches_the_oracle(scene_name):
     assert np.isfinite(img).all() and not np.allclose(img, plain)
     assert np.isclose(img, ref, rtol=2e-3, atol=1e-5).all(axis=2).mean() > 0.99
     assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 2e-3
+
+
+@pytest.mark.gpu
+def test_gpu_gather_on_the_reference_tests_point_sets():
+    """The point sets and targets of raytracer/test/KDTree.cpp:20-163 / test/KDTreeBuilder.cpp:20-38 through
+    rtgpu_scene_set_photons + rtgpu_scene_gather_photons.  The library's gather always asks for 20 neighbours (what
+    DiffuseMaterial asks for), so every point of a set is found: count = the set's size, max_dist = FLT_MAX (the list
+    never fills, photonmapping/KDTree.h:243-247), and the energies are summed nearest first -- in the order the oracle's
+    walk of the reference's hand-built tree returns them (checked against the reference's expectations on the CPU side)."""
+    from kdtree_vectors import CASES
+    sc, _, _ = grey_box(0.5)
+    energies = np.array([[2.0 ** 24, 1.0, 3.0], [1.0, 2.0 ** 24, -3.0], [-(2.0 ** 24), 1.0, 0.5], [0.5, -(2.0 ** 24), 2.0 ** 24]], np.float32)
+    S = oracle.OracleScene(sc)
+    with api.Scene(sc) as g:
+        for name, pts, c0, c1, ax, target, count, order, _ in CASES:
+            n = len(pts)
+            ph = np.zeros(n, dtype=abi.PHOTON_DTYPE)
+            ph["pos"] = np.asarray(pts, np.float32)
+            ph["normal"] = (0.0, 1.0, 0.0)
+            ph["energy"] = energies[:n]
+            g.set_photons(ph, abi.PM_FULL, 0)
+            S.set_photons(ph, abi.PM_FULL, 0)
+            q = np.asarray([target], np.float32)
+            d = np.asarray([[0.0, 1.0, 0.0]], np.float32)
+            got, ref = g.gather_photons(q, d)[0], S.gather_photons(q, d)[0]
+            found, _, full_order = oracle.kd_nearest_explicit(pts, c0, c1, ax, target, n)
+            assert found == n and full_order[:count].tolist() == order, name
+            want = np.zeros(3, np.float32)
+            for i in full_order:
+                want = (want + energies[i]).astype(np.float32)
+            assert got["count"] == n and got["max_dist"] == np.finfo(np.float32).max, name
+            assert np.array_equal(got["energy"], want), (name, got["energy"], want)
+            assert got["count"] == ref["count"] and got["max_dist"] == ref["max_dist"] and np.array_equal(got["energy"], ref["energy"]), name
+            # a direction no photon faces: nothing is found and the radius stays at the caller's 1e9
+            none = g.gather_photons(q, -d)[0]
+            assert none["count"] == 0 and none["max_dist"] == np.float32(1e9)
