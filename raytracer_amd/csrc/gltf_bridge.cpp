@@ -613,19 +613,28 @@ struct Loader {
 
     // one accessor read the way loadIndicesImpl / loadVec3s / loadVec2s walk it (io/GLTF.cpp:33-138): from the
     // accessor's start to the end of its buffer view, one element per stride
+    // A byte offset / length / stride of the file as a size: the JSON number must be finite, non-negative and an
+    // integer below 2^53 (a double holds those exactly; anything else would make the cast undefined or the sums wrap).
+    static size_t byte_count(const Json& obj, const char* name)
+    {
+        const double v = obj.get_num(name, 0);
+        if (!(v >= 0.0) || !(v < 9007199254740992.0) || v != std::floor(v)) throw std::runtime_error(std::string("glTF: bad ") + name);
+        return (size_t)v;
+    }
     template <typename F>
     void walk_accessor(const Json& acc, size_t elemSize, F&& f)
     {
         const Json& bv = item("bufferViews", acc.get_int("bufferView", -1));
-        const size_t start = (size_t)bv.get_num("byteOffset", 0) + (size_t)acc.get_num("byteOffset", 0);
-        const size_t end = (size_t)bv.get_num("byteLength", 0) + (size_t)bv.get_num("byteOffset", 0);
-        size_t stride = (size_t)bv.get_num("byteStride", 0);
+        const size_t viewOff = byte_count(bv, "byteOffset");
+        const size_t start = viewOff + byte_count(acc, "byteOffset");   // both < 2^53: no wrap
+        const size_t end = viewOff + byte_count(bv, "byteLength");
+        size_t stride = byte_count(bv, "byteStride");
         if (stride == 0) stride = elemSize;
         const int bi = bv.get_int("buffer", -1);
         if (bi < 0 || (size_t)bi >= buffers.size()) throw std::runtime_error("glTF: buffer index out of range");
         const std::vector<uint8_t>& buf = buffers[(size_t)bi];
         for (size_t i = start; i < end; i += stride) {
-            if (i + elemSize > buf.size()) throw std::runtime_error("glTF: accessor reads past its buffer");
+            if (i > buf.size() || elemSize > buf.size() - i) throw std::runtime_error("glTF: accessor reads past its buffer");
             f(buf.data() + i);
         }
     }
@@ -692,8 +701,9 @@ struct Loader {
             const Json& bv = item("bufferViews", img.get_int("bufferView", -1));
             const int bi = bv.get_int("buffer", -1);
             if (bi < 0 || (size_t)bi >= buffers.size()) throw std::runtime_error("glTF: buffer index out of range");
-            const size_t off = (size_t)bv.get_num("byteOffset", 0), len = (size_t)bv.get_num("byteLength", 0);
-            if (off + len > buffers[(size_t)bi].size()) throw std::runtime_error("glTF: image view past its buffer");
+            const size_t off = byte_count(bv, "byteOffset"), len = byte_count(bv, "byteLength");
+            const size_t have = buffers[(size_t)bi].size();
+            if (off > have || len > have - off) throw std::runtime_error("glTF: image view past its buffer");
             bytes.assign(buffers[(size_t)bi].begin() + (std::ptrdiff_t)off, buffers[(size_t)bi].begin() + (std::ptrdiff_t)(off + len));
         } else {
             bytes = load_uri(img.get_str("uri"));
@@ -1119,6 +1129,8 @@ int rtgpu_gltf_load(const char* glb_path, float image_aspect_ratio, int soupify_
         finish(*g);
     } catch (const Unsupported& e) {
         return rt::set_error(RTGPU_ERR_UNSUPPORTED, e.what());
+    } catch (const std::bad_alloc&) {
+        return rt::set_error(RTGPU_ERR_OUT_OF_MEMORY, "out of host memory");
     } catch (const std::exception& e) {
         return rt::set_error(RTGPU_ERR_IO, e.what());
     }

@@ -83,6 +83,7 @@ extern "C" {
 int rtgpu_write_exr(const char* path, const float* rgb, int32_t width, int32_t height, int full_floats)
 {
     if (!path || !rgb || width <= 0 || height <= 0) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "bad image arguments");
+    return rt::guarded([&]() -> int {   // the frame-sized vectors below can fail to allocate
     std::vector<uint8_t> out;
     const uint8_t magic[8] = {0x76, 0x2f, 0x31, 0x01, 2, 0, 0, 0};
     put(out, magic, 8);
@@ -127,11 +128,13 @@ int rtgpu_write_exr(const char* path, const float* rgb, int32_t width, int32_t h
     }
     if (!write_all(path, out)) return rt::set_error(RTGPU_ERR_IO, std::string("cannot write ") + path);
     return RTGPU_OK;
+    });
 }
 
 int rtgpu_write_png(const char* path, const float* rgb, int32_t width, int32_t height, double exposure, double gamma)
 {
     if (!path || !rgb || width <= 0 || height <= 0) return rt::set_error(RTGPU_ERR_INVALID_ARGUMENT, "bad image arguments");
+    return rt::guarded([&]() -> int {
     const double exposureFactor = std::pow(2, exposure);
     std::vector<uint8_t> raw;
     raw.reserve(((size_t)width * 3 + 1) * height);
@@ -162,6 +165,7 @@ int rtgpu_write_png(const char* path, const float* rgb, int32_t width, int32_t h
     png_chunk(out, "IEND", {});
     if (!write_all(path, out)) return rt::set_error(RTGPU_ERR_IO, std::string("cannot write ") + path);
     return RTGPU_OK;
+    });
 }
 
 } // extern "C"

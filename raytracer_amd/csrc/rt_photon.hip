@@ -9,14 +9,20 @@
 //            scene with the wave-cooperative closest-hit query, so lanes whose photons left the scene still
 //            help the others.  A vertex that stores a photon writes slot [ray][vertex]; the host keeps the
 //            filled slots in (light, ray, vertex) order, so the map does not depend on scheduling.
-//   tree   : the reference sorts each slice along the next axis (y, z, x, ...) and takes the element at count / 2.
-//            The same tree is kept here without pointers: photons are permuted so that every range [lo, hi) has
-//            its axis median at lo + (hi - lo) / 2 (std::nth_element, host threads for the upper levels).
-//   gather : one lane per query point, depth-first in the reference's order (near side, node, far side) with a stack
+//   tree   : the reference sorts each slice along the next axis (y, z, x, ...) and takes the element at count / 2
+//            (a slice of two keeps its first element, with the parent's axis, and hangs the second to the right:
+//            photonmapping/KDTreeBuilder.h:178-231).  Here a median tree of the same kind -- not node for node the
+//            reference's -- is kept without pointers: photons are permuted so that every range [lo, hi) has its axis
+//            median at lo + (hi - lo) / 2 (std::nth_element at every level, two-element ranges included; host threads
+//            for the upper levels), and far sides are pruned by the distance to the split plane where the reference
+//            uses the distance to the node's box.
+//   gather : one lane per query point, depth-first near side, node, far side (the reference's visiting pattern) with a stack
 //            of far ranges in private memory and a bounded max-heap of the k best; ranges whose cone of photon
 //            normals cannot pass the query's filter are skipped.  A query that needs more than a budget of nodes is
 //            answered again by a whole wave (gather_photons_wave).  The k nearest photons that pass the filter are
-//            the same set whatever the tree and the order of the search, distance ties aside.
+//            the same set whatever the tree and the order of the search; which photon wins a distance tie at the
+//            k-th place, and the last bits of an energy sum whose terms tie in distance, depend on the tree: parity
+//            with the reference there is unpinned (no fixture of the reference covers photon-mapped output).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -371,7 +377,7 @@ struct Dev {
 #define PH_HIP(call)                                                                                   \
     do {                                                                                               \
         hipError_t e_ = (call);                                                                        \
-        if (e_ != hipSuccess) return set_error(RTGPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
+        if (e_ != hipSuccess) return set_error(e_ == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_)); \
     } while (0)
 
 } // namespace

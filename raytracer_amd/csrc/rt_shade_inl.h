@@ -52,7 +52,10 @@ __device__ __forceinline__ F3 cosine_hemisphere(float r1, float r2)
     return f3((float)(1.0f * sin_theta * cos_phi), (float)(1.0f * sin_theta * sin_phi), 1.0f * cos_theta);
 }
 
-// sampleP22, material/VNDFGGXSampler.cpp:7-43
+// sampleP22, material/VNDFGGXSampler.cpp:7-43.  Provenance: this is the slope-sampling routine for the GGX
+// distribution of visible normals published by E. Heitz and E. d'Eon, "Importance Sampling Microfacet-Based BSDFs
+// using the Distribution of Visible Normals" (EGSR 2014, supplemental material); the fitted constants of the
+// rational approximation are the paper's, and the arithmetic keeps the reference's order so that samples agree.
 __device__ __forceinline__ void sample_p22(double theta_i, double U1, double U2, float& sx, float& sy)
 {
     if (theta_i < 0.0001) {

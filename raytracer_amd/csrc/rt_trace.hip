@@ -27,34 +27,31 @@ __device__ __forceinline__ uint64_t interleave8(uint64_t p, uint64_t nb8)
 }
 static inline uint64_t interleave_blocks(uint64_t n) { return (n >> 3) & ~7ull; }
 
-template <bool INSTANCED, bool COUNT, int BLOCK, bool PERSIST>
-__global__ __launch_bounds__(BLOCK) void trace_closest_kernel(SceneView sv, const float* __restrict__ ro,
-                                                              const float* __restrict__ rd, uint64_t n,
-                                                              rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
+template <bool INSTANCED, bool COUNT>
+__global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const float* __restrict__ ro,
+                                                           const float* __restrict__ rd, uint64_t n,
+                                                           rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
 {
-    __shared__ int stackAll[BLOCK / 64][kLdsStack][64];
-    const int lane = threadIdx.x & 63;
-    int (*stack)[64] = stackAll[threadIdx.x >> 6];
-    const uint64_t stride = PERSIST ? (uint64_t)gridDim.x * BLOCK : 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += stride) {
-        F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
-        F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
-        uint32_t nb = 0, nt = 0;
-        TraceResult r;
-        if (INSTANCED && sv.refTop) r = trace_ray_reftop_closest<COUNT>(sv, o, d, stack, lane, nb, nt);
-        else r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
-        rtgpu_hit h;
-        h.t = r.t;
-        h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
-        h.inst = r.inst;
-        h.beta = r.beta;
-        h.gamma = r.gamma;
-        out[i] = h;
-        if (COUNT) {
-            counts[2 * i] = nb;
-            counts[2 * i + 1] = nt;
-        }
-        if (!PERSIST) break;
+    __shared__ int stack[kLdsStack][64];
+    const int lane = threadIdx.x;
+    const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    F3 o = f3(ro[3 * i], ro[3 * i + 1], ro[3 * i + 2]);
+    F3 d = f3(rd[3 * i], rd[3 * i + 1], rd[3 * i + 2]);
+    uint32_t nb = 0, nt = 0;
+    TraceResult r;
+    if (INSTANCED && sv.refTop) r = trace_ray_reftop_closest<COUNT>(sv, o, d, stack, lane, nb, nt);
+    else r = trace_ray<INSTANCED, false, COUNT>(sv, o, d, INFINITY, stack, lane, nb, nt);
+    rtgpu_hit h;
+    h.t = r.t;
+    h.prim = r.slot != kInvalid ? sv.triIds[r.slot] : kInvalid;
+    h.inst = r.inst;
+    h.beta = r.beta;
+    h.gamma = r.gamma;
+    out[i] = h;
+    if (COUNT) {
+        counts[2 * i] = nb;
+        counts[2 * i + 1] = nt;
     }
 }
 
@@ -197,22 +194,9 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
                                 rtgpu_hit* dHits, uint32_t* dCounts, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
+    // RTGPU_TRACE_VARIANT=-1 forces the per-lane walk (one lane per ray, no cooperation): the comparison point of the
+    // cooperative kernels and a second implementation of the same result definition for the determinism checks
     static const int variant = env_int("RTGPU_TRACE_VARIANT", 0);
-    if (sv.singleMesh && !dCounts && variant > 0 && variant < 4) {
-        if (variant == 1) { // 256-thread blocks
-            dim3 grid((unsigned)((n + 255) / 256)), block(256);
-            hipLaunchKernelGGL((trace_closest_kernel<false, false, 256, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        } else if (variant == 2) { // persistent waves
-            const int waves = env_int("RTGPU_TRACE_WAVES", 256 * 20);
-            dim3 grid((unsigned)waves), block(64);
-            hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        } else { // persistent 256-thread blocks
-            const int blocks = env_int("RTGPU_TRACE_WAVES", 256 * 5);
-            dim3 grid((unsigned)blocks), block(256);
-            hipLaunchKernelGGL((trace_closest_kernel<false, false, 256, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        }
-        return hipGetLastError();
-    }
     const uint64_t blocks = (n + 63) / 64;
     if (blocks > 0x7FFFFFFFull) return hipErrorInvalidValue;
     dim3 grid((unsigned)blocks), block(64);
@@ -228,7 +212,7 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
     if (sv.singleMesh && variant != -1 && (!dCounts || countCooperative)) {
         const uint64_t nb8 = interleave_blocks(n);
         if (dCounts) hipLaunchKernelGGL((trace_closest_steal_kernel<true>), grid, block, 0, stream, sv, dO, dD, n, nb8, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, (size_t)env_int("RTGPU_TRACE_EXTRA_LDS", 0), stream, sv, dO, dD, n, nb8, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_steal_kernel<false>), grid, block, 0, stream, sv, dO, dD, n, nb8, dHits, dCounts);
         return hipGetLastError();
     }
     if (sv.coopInstanced && variant != -1 && !dCounts) {
@@ -236,11 +220,11 @@ hipError_t launch_trace_closest(const SceneView& sv, const float* dO, const floa
         return hipGetLastError();
     }
     if (sv.singleMesh) {
-        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_kernel<false, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<false, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<false, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
     } else {
-        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<true, true, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
-        else hipLaunchKernelGGL((trace_closest_kernel<true, false, 64, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        if (dCounts) hipLaunchKernelGGL((trace_closest_kernel<true, true>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
+        else hipLaunchKernelGGL((trace_closest_kernel<true, false>), grid, block, 0, stream, sv, dO, dD, n, dHits, dCounts);
     }
     return hipGetLastError();
 }

@@ -604,6 +604,40 @@ def test_damaged_files_are_refused_not_crashed_on(tmp_path):
     assert outcomes["error"] > 50 and outcomes["ok"] + outcomes["error"] == 400
 
 
+def _rewrite_json(path, out_path, edit):
+    """A copy of a .glb whose JSON chunk went through `edit` (the binary chunk is kept)."""
+    import json
+    data = open(path, "rb").read()
+    json_len = struct.unpack_from("<I", data, 12)[0]
+    doc = json.loads(data[20:20 + json_len].decode("utf-8"))
+    edit(doc)
+    js = json.dumps(doc).encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    rest = data[20 + json_len:]
+    body = struct.pack("<II", len(js), 0x4E4F534A) + js + rest
+    open(out_path, "wb").write(struct.pack("<III", 0x46546C67, 2, 12 + len(body)) + body)
+
+
+@pytest.mark.parametrize("field,value", [("view.byteLength", -1), ("view.byteOffset", -8), ("accessor.byteOffset", -12),
+                                         ("view.byteLength", 1e300), ("view.byteOffset", 2.0 ** 63), ("view.byteStride", -4),
+                                         ("accessor.byteOffset", 0.5), ("view.byteOffset", float("nan"))])
+def test_negative_huge_and_fractional_byte_counts_are_refused(tmp_path, field, value):
+    """Offsets, lengths and strides are JSON numbers: negative, non-finite, fractional or huge ones must be an error,
+    not a wrapped sum that passes the bounds check (a byteLength of -1 with an accessor offset of -12 used to read in
+    front of the buffer)."""
+    path, _, _ = _full_scene(str(tmp_path))
+    bad = os.path.join(str(tmp_path), "bad_counts.glb")
+
+    def edit(doc):
+        where, name = field.split(".")
+        for obj in (doc["bufferViews"] if where == "view" else doc["accessors"]):
+            obj[name] = value
+    _rewrite_json(path, bad, edit)   # (Python writes a NaN as the bare word NaN, as sloppy exporters do)
+    with pytest.raises((api.RtgpuError, ValueError)):
+        with gltf.load_glb(bad, 1.5, soupify=False) as g:
+            g.scene_data()
+
+
 def test_loader_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     """tests/native/fuzz_gltf.cpp: the loader's source built for the host with -fsanitize=address,undefined and run on
     1500 damaged copies of a valid file; any out-of-bounds access or undefined operation aborts the harness."""
