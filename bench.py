@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
 """Benchmark of the ray-tracing hot path on MI355X.
 
-Default workload (BASELINE.json configs[1]): a ~1.31 M-triangle fractal-displaced icosphere,
-1920x1080 primary rays (one per pixel), closest-hit traversal on one GPU.  A step is one pass
-of the closest-hit kernel over the whole frame's rays, which are resident in HBM before the
-timed region starts.  With N > 1 ranks (torch.distributed, one process per GPU) every rank
-traces its own full frame of jittered primary rays (weak scaling, no data-path collective) and
-the reported value is the total over ranks divided by the slowest rank's time.
+Headline (every N): one path-traced frame of the ~1.31 M-triangle blob-in-a-room scene -- 3840x2160, 8x8 = 64
+samples per pixel, path length 9, diffuse + glossy, one area and one point light -- i.e. incoherent extension and
+shadow rays on a ~1 M-triangle scene.  A step is one frame.  The frame is cut into 32x32 squares shared out over the
+ranks (one process per GPU, scene replicated, strong scaling); every rank renders its squares into a compact buffer
+and the buffers are gathered on rank 0 by the library's RCCL send / receive pairs inside the timed region.
+value = rays traced (primary + extension + shadow, every query counted once) by all ranks / wall time.
+
+At N = 1 the line also carries: the roofline of the dominant kernel (trace_stage_kernel: algorithmic bytes from a
+counting render / the stage's device time from a profiling render, both live), the CPU baseline (the oracle on a tile
+of the same frame) and, under "extras", the other configurations of BASELINE.json with a roofline each:
+configs[1] coherent primary rays and bounce rays on the blob, configs[2] the interior frame, configs[4] the
+49.8 M-triangle cluster.
 
 Prints one JSON line (rank 0).
 """
@@ -14,6 +20,7 @@ import argparse
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
@@ -21,77 +28,339 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
+L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
+MALL_BYTES = 256 << 20  # Infinity Cache: scenes below this size are served on-die, HBM is not what binds them
+TILE = 32
 
 
-def bench_frame(torch, dist, dev, rank, world, all_reduce, frames=3):
-    """ms/frame at fixed spp on configs[2]: the interior scene (~250 k triangles, diffuse + glossy, one
-    area and one point light), 1920x1080, 8x8 samples per pixel, path length 9.  The frame is cut into
-    interleaved row bands over the ranks (strong scaling) and gathered to rank 0 inside the timed region."""
-    from raytracer_amd import abi, api, distributed, scenes
+def ray_bytes(rays, boxes, tris, out_bytes):
+    """Algorithmic bytes of a class of rays: 32 B ray in, `out_bytes` out, 32 B per child box and 36 B per triangle tested
+    by the ray traversed on its own."""
+    return (32.0 + out_bytes) * rays + 32.0 * boxes + 36.0 * tris
 
-    W, H, G, M = 1920, 1080, 8, 8
-    sc, cam_m, yfov = scenes.interior_scene(scenes.C3_DETAIL)
+
+def roofline(alg_bytes, kernel_ms, scene_bytes, kernel, extra=None):
+    """bound = the memory level the scene's size puts the traversal in: HBM when the scene is larger than the Infinity
+    Cache, else L2 (a tree walk re-reads the upper levels, which the caches serve: "achieved" is the algorithmic rate
+    against the bandwidth of that level)."""
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    hbm = scene_bytes > MALL_BYTES and achieved < HBM_PEAK_GBS
+    peak = HBM_PEAK_GBS if hbm else L2_PEAK_GBS
+    out = {"bound": "hbm" if hbm else "l2", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+           "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
+           "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "scene_bytes": scene_bytes}
+    if extra:
+        out.update(extra)
+    return out
+
+
+def committed_counters(tag):
+    """PMC figures of profiles/<tag>_pmc_summary.json (collected by scripts/gpu_profile.sh in separate rocprofv3 --pmc
+    passes of this program; NOT measured in this run)."""
+    path = os.path.join(HERE, "profiles", tag + "_pmc_summary.json")
+    try:
+        return json.load(open(path)), os.path.relpath(path, HERE)
+    except Exception:
+        return None, None
+
+
+def frame_rooflines(torch, api, abi, scene, cam, st, dev, info, kernel_name):
+    """Counting render + profiling render of one frame -> roofline of the trace stage and the stage split."""
+    fb = torch.zeros((st.height, st.width, 3), dtype=torch.float32, device=dev)
+    r = api.Renderer()
+    work = r.render_work_device(scene, cam, st, fb)
+    prof = r.render_profile_device(scene, cam, st, fb)
+    del fb
+    ext = ray_bytes(work.extension_rays, work.extension_boxes, work.extension_triangles, 16.0)
+    shd = ray_bytes(work.shadow_rays, work.shadow_boxes, work.shadow_triangles, 4.0)
+    n_ext, n_shd = max(1, work.extension_rays), max(1, work.shadow_rays)
+    rl = roofline(ext + shd, prof.trace_ms, int(info.device_bytes), kernel_name, {
+        "kernel_ms_avg_per_launch": prof.trace_ms / max(1, prof.trace_launches), "launches_per_frame": prof.trace_launches,
+        "extension": {"rays": work.extension_rays, "boxes_per_ray": work.extension_boxes / n_ext, "tris_per_ray": work.extension_triangles / n_ext,
+                      "bytes_per_ray": ext / n_ext},
+        "shadow": {"rays": work.shadow_rays, "boxes_per_ray": work.shadow_boxes / n_shd, "tris_per_ray": work.shadow_triangles / n_shd,
+                   "bytes_per_ray": shd / n_shd},
+        "stage_mrays_per_s": (work.extension_rays + work.shadow_rays) / prof.trace_ms / 1e3,
+        "measured": "counting render + profiling render (one batch in flight, HIP events around every launch) in this run"})
+    stages = {"primary_ms": prof.primary_ms, "shade_ms": prof.shade_ms, "trace_ms": prof.trace_ms, "gather_ms": prof.gather_ms,
+              "resolve_ms": prof.resolve_ms, "total_ms": prof.total_ms,
+              # shade stage: 64 B in / 48 B out per path vertex shaded (one vertex per path and pass)
+              "shade_GBps": (work.extension_rays + work.primary_rays * st.material_aa) * 112.0 / max(prof.shade_ms, 1e-9) / 1e6}
+    return rl, stages
+
+
+def native_comm(torch, dist, api, rank, world, dev, timeout_s=90.0):
+    """The library's RCCL communicator for this rank, checked with a small gather before anything is timed.  Made in a
+    helper thread so that a rendezvous that never completes cannot hold the benchmark: returns (comm or None, note)."""
+    from raytracer_amd import abi, distributed
+    ident = torch.zeros(api.COMM_ID_BYTES, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        ident.copy_(torch.tensor(list(api.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(ident, 0)
+    ident_bytes = bytes(ident.cpu().numpy().tolist())
+    box = {}
+
+    def make():
+        try:
+            api.set_device(dev.index)
+            torch.cuda.set_device(dev)
+            comm = api.Comm(ident_bytes, rank, world)
+            W, H, T = 67, 45, 8
+            st = abi.make_settings(W, H)
+            ys, xs, cs = np.arange(H)[:, None, None], np.arange(W)[None, :, None], np.arange(3)[None, None, :]
+            pattern = (ys * 1000 + xs * 3 + cs + 1).astype(np.float32)
+            local = torch.from_numpy(distributed.compact_from_frame(pattern, st, T, rank, world)).to(dev)
+            frame = torch.zeros((H, W, 3), dtype=torch.float32, device=dev) if rank == 0 else None
+            s = torch.cuda.Stream(device=dev)
+            comm.gather_tiles_device(st, T, local, frame, s)
+            s.synchronize()
+            if rank == 0 and not np.array_equal(frame.cpu().numpy(), pattern):
+                raise RuntimeError("the gathered frame differs from the pattern")
+            box["comm"] = comm
+        except Exception as e:  # noqa: BLE001
+            box["error"] = "%s: %s" % (type(e).__name__, e)
+
+    th = threading.Thread(target=make, daemon=True)
+    th.start()
+    th.join(timeout_s)
+    ok = 1.0 if ("comm" in box and not th.is_alive()) else 0.0
+    flag = torch.tensor([ok], dtype=torch.float64, device=dev)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if float(flag.item()) == 1.0:
+        return box["comm"], "rtgpu_gather_tiles_device: RCCL ncclSend / ncclRecv pairs to rank 0 + scatter kernel"
+    why = box.get("error", "timed out after %.0f s" % timeout_s if th.is_alive() else "failed on another rank")
+    sys.stderr.write("rank %d: native communicator unusable (%s); gathering with torch.distributed instead\n" % (rank, why))
+    return None, "torch.distributed gather (the library's communicator was unusable: %s)" % why
+
+
+def bench_headline(args, torch, dist, api, abi, scenes, rank, world, dev):
+    from raytracer_amd import distributed
+    W, H, G, M = args.width, args.height, args.gaa, args.maa
+    sc, cam_m, yfov = scenes.blob_room_scene(args.subdiv)
     cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
     scene = api.Scene(sc)
+    info = scene.info()
     st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1)
-    bpr = 1 if world == 1 else 4
-    # pre-flight on every rank before any collective of this section: a rank that cannot render must
-    # not leave the others waiting in the gather
+
+    # pre-flight on every rank before any collective: a rank that cannot render must not leave the others waiting
     ok = 1.0
     try:
-        probe = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-        api.Renderer().render_device(scene, cam, abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1,
-                                                                  tile=(0, 0, 64, 8)), probe, torch.cuda.current_stream())
+        probe = torch.zeros(api.tile_buffer_floats(abi.make_settings(W, H, tile=(0, 0, 64, 32)), TILE, 0, 1), dtype=torch.float32, device=dev)
+        api.Renderer().render_tiles_device(scene, cam, abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1, tile=(0, 0, 64, 32)),
+                                           TILE, 0, 1, probe)
         torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         ok = 0.0
-        sys.stderr.write("frame pre-flight failed on rank %d: %s\n" % (rank, e))
+        sys.stderr.write("pre-flight render failed on rank %d: %s\n" % (rank, e))
+    comm, gather_note = None, "one rank: scatter kernel only"
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")   # where the benchmark's own small collectives live
     if world > 1:
-        flag = torch.tensor([ok], dtype=torch.float64, device=dev)
-        all_reduce(flag, dist.ReduceOp.MIN)
-        ok = float(flag.item())
-    if ok == 0.0:
-        scene.close()
-        return {"error": "frame pre-flight failed on some rank (see stderr)"}
-    times, rays = [], 0
-    for k in range(frames + 1):  # the first frame is the warm-up
+        flag = torch.tensor([ok], dtype=torch.float64, device=cdev)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if float(flag.item()) == 0.0:
+            raise SystemExit("pre-flight render failed on some rank (see stderr)")
+        if args.backend == "nccl":
+            comm, gather_note = native_comm(torch, dist, api, rank, world, dev)
+        else:
+            gather_note = "torch.distributed gather over %s (rehearsal: ranks share a GPU)" % args.backend
+    elif ok == 0.0:
+        raise SystemExit("pre-flight render failed")
+    if world == 1:
+        comm = api.Comm(api.comm_unique_id(), 0, 1)
+    sharder = distributed.FrameSharder(scene, rank, world, dev, comm=comm, tile_size=TILE)
+
+    def frame():
+        return sharder.render(cam, st)
+
+    for _ in range(args.warmup):
+        frame()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    rays = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out, stats = frame()
+        rays += stats.primary_rays + stats.extension_rays + stats.shadow_rays
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+        rr = torch.tensor([float(rays)], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dist.all_reduce(rr, op=dist.ReduceOp.SUM)
+        elapsed, rays = float(tt.item()), float(rr.item())
+    checks = {}
+    if rank == 0:
+        img = out if isinstance(out, np.ndarray) else out.cpu().numpy()
+        finite = np.isfinite(img)
+        checks = {"frame_mean": float(img[finite].mean()), "non_finite_pixels": int((~finite).any(axis=2).sum())}
+    res = {"scene": sc, "cam": cam, "st": st, "handle": scene, "info": info, "elapsed": elapsed, "rays": float(rays),
+           "gather": gather_note, "checks": checks, "frame": img if rank == 0 else None}
+    return res
+
+
+def bench_c2(args, torch, api, abi, scenes, dev):
+    """configs[1]: closest hit for 1920x1080 primary rays of the blob alone (coherent), and for diffuse-bounce rays leaving
+    its surface (incoherent)."""
+    W, H = 1920, 1080
+    sc, cam_m, yfov = scenes.blob_scene(args.subdiv)
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    scene = api.Scene(sc)
+    info = scene.info()
+    stream = torch.cuda.current_stream()
+    n = W * H
+    st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    d_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    api.generate_primary_device(cam, st, 0, d_o, d_d, stream)
+    torch.cuda.synchronize()
+
+    def timed(d_o, d_d, reps=20):
+        m = d_o.shape[0]
+        hits = torch.empty((m, 5), dtype=torch.int32, device=dev)
+        cnt = torch.zeros((m, 2), dtype=torch.int32, device=dev)
+        scene.trace_counts_device(d_o, d_d, m, cnt, stream)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        t0 = time.perf_counter()
-        frame, tot = distributed.render_frame_distributed(scene, cam, st, rank, world, dev, bands_per_rank=bpr)
+        boxes, tris = cnt.to(torch.float64).sum(dim=0).tolist()
+        for _ in range(3):
+            scene.trace_rays_device(d_o, d_d, m, hits, stream)
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        dt = time.perf_counter() - t0
-        r = float(tot["primary_rays"] + tot["extension_rays"] + tot["shadow_rays"])
-        if world > 1:
-            t_max = torch.tensor([dt], dtype=torch.float64, device=dev)
-            r_sum = torch.tensor([r], dtype=torch.float64, device=dev)
-            all_reduce(t_max, dist.ReduceOp.MAX)
-            all_reduce(r_sum, dist.ReduceOp.SUM)
-            dt, r = float(t_max.item()), float(r_sum.item())
-        if k > 0:
-            times.append(dt)
-            rays = r
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record(stream)
+        for k in range(reps):
+            scene.trace_rays_device(d_o, d_d, m, hits, stream)
+            ev[k + 1].record(stream)
+        torch.cuda.synchronize()
+        ms = float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
+        return ms, boxes, tris, hits
+
+    out = {}
+    ms, boxes, tris, hits = timed(d_o, d_d)
+    counters, src = committed_counters(args.profile_tag)
+    extra = {"kernel_ms_avg_per_launch": ms, "boxes_per_ray": boxes / n, "tris_per_ray": tris / n, "measured": "HIP events around each launch in this run"}
+    if counters and "c2_primary" in counters:
+        extra["counters"] = dict(counters["c2_primary"], source="committed profile " + src + " (not measured in this run)")
+    out["primary"] = {"workload": "configs[1]: %d triangles, %dx%d primary rays, closest hit" % (sc.n_triangles(), W, H),
+                      "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
+                      "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
+    # bounce rays: from every primary hit point, a direction in the hemisphere of the (radial) outward normal
+    h = hits.cpu().numpy().view(np.uint32)
+    hit = h[:, 2] != 0xFFFFFFFF
+    o, d = d_o.cpu().numpy()[hit], d_d.cpu().numpy()[hit]
+    t = h[hit, 0].view(np.float32)
+    hp = (o + d * t[:, None]).astype(np.float32)
+    rng = np.random.RandomState(1)
+    reps = int(np.ceil(n / len(hp)))
+    so = np.tile(hp, (reps, 1))[:n]
+    nn = so / np.linalg.norm(so, axis=1, keepdims=True)
+    so = (so + nn * 1e-3).astype(np.float32)
+    sd = rng.normal(size=so.shape)
+    sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+    sd[(sd * nn).sum(1) < 0] *= -1
+    b_o, b_d = torch.from_numpy(so).to(dev), torch.from_numpy(sd.astype(np.float32)).to(dev)
+    ms, boxes, tris, _ = timed(b_o, b_d)
+    extra = {"kernel_ms_avg_per_launch": ms, "boxes_per_ray": boxes / n, "tris_per_ray": tris / n, "measured": "HIP events around each launch in this run"}
+    if counters and "c2_bounce" in counters:
+        extra["counters"] = dict(counters["c2_bounce"], source="committed profile " + src + " (not measured in this run)")
+    out["bounce"] = {"workload": "configs[1] scene, %d diffuse-bounce rays from the primary hit points in pixel order (incoherent)" % n,
+                     "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
+                     "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
+    # the host-pointer entry point (rays and hits cross PCIe inside the call)
+    o_h, d_h = d_o.cpu().numpy(), d_d.cpu().numpy()
+    scene.trace_rays(o_h, d_h)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        scene.trace_rays(o_h, d_h)
+    out["primary_host_pointers_mrays_per_s"] = 3 * n / (time.perf_counter() - t0) / 1e6
     scene.close()
-    ms = float(np.mean(times)) * 1e3
-    return {"workload": "configs[2]: interior scene, %d triangles, %dx%d, %dx%d spp, path length 9, row bands over %d GPU(s) + gather"
-                        % (sc.n_triangles(), W, H, G, M, world),
-            "ms_per_frame": ms, "mrays_per_s": rays / ms / 1e3, "rays_per_frame": rays, "frames": frames, "scaling": "strong"}
+    return out
+
+
+def bench_frame(torch, api, abi, scene_data, cam_m, yfov, W, H, G, M, dev, label, kernel_name, frames=3):
+    from raytracer_amd import scenes
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    scene = api.Scene(scene_data)
+    info = scene.info()
+    st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, max_path_length=9, seed=1)
+    fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+    r = api.Renderer()
+    r.render_device(scene, cam, st, fb)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    rays = 0
+    for _ in range(frames):
+        s = r.render_device(scene, cam, st, fb)
+        rays = s.primary_rays + s.extension_rays + s.shadow_rays
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / frames * 1e3
+    del fb
+    rl, stages = frame_rooflines(torch, api, abi, scene, cam, st, dev, info, kernel_name)
+    out = {"workload": label % scene_data.n_triangles(), "ms_per_frame": ms, "mrays_per_s": rays / ms / 1e3, "rays_per_frame": rays,
+           "scene_hbm_bytes": int(info.device_bytes), "scene_build_ms": float(info.build_ms), "roofline": rl, "stages_one_batch_in_flight": stages}
+    scene.close()
+    return out
+
+
+def cpu_baseline(res, abi, api, torch, dev):
+    """The oracle on a tile of the headline frame (same scene, camera, samples, seed), its host threads on the GPU box's cores;
+    the GPU renders the same tile and the two images are compared."""
+    import oracle
+    threads = oracle.default_threads()
+    st0 = res["st"]
+    t0 = time.perf_counter()
+    osc = oracle.OracleScene(res["scene"], threads=threads)
+    build_s = time.perf_counter() - t0
+    W, H = st0.width, st0.height
+
+    def tile_settings(tw, th):
+        x0, y0 = (W - tw) // 2, (H - th) // 2
+        return abi.make_settings(W, H, geometry_aa=st0.geometry_aa, material_aa=st0.material_aa, max_path_length=st0.max_path_length,
+                                 seed=st0.seed, tile=(x0, y0, x0 + tw, y0 + th))
+
+    st = tile_settings(48, 27)
+    t0 = time.perf_counter()
+    _, stats = osc.render(res["cam"], st, threads=threads)
+    dt = time.perf_counter() - t0
+    rate = (stats.primary_rays + stats.extension_rays + stats.shadow_rays) / dt
+    # second tile sized for about 12 s at that rate
+    scale = max(1.0, min(12.0, (12.0 / max(dt, 1e-3)) ** 0.5))
+    tw, th = int(48 * scale) // 2 * 2, int(27 * scale) // 2 * 2
+    st = tile_settings(tw, th)
+    t0 = time.perf_counter()
+    ref, stats = osc.render(res["cam"], st, threads=threads)
+    dt = time.perf_counter() - t0
+    rays = stats.primary_rays + stats.extension_rays + stats.shadow_rays
+    got = res["frame"][st.y_start:st.y_end, st.x_start:st.x_end]
+    want = ref[st.y_start:st.y_end, st.x_start:st.x_end]
+    fin = np.isfinite(want).all(axis=2) & np.isfinite(got).all(axis=2)
+    rel_rmse = float(np.sqrt(np.mean((got[fin] - want[fin]) ** 2)) / max(want[fin].mean(), 1e-12))
+    return {"value": rays / dt / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+            "sample": "a %dx%d tile in the middle of the same frame (same samples per pixel, path length and random numbers): %d rays in %.1f s; "
+                      "tree build %.1f s excluded" % (tw, th, rays, dt, build_s),
+            "first_estimate_mrays_per_s": rate / 1e6, "gpu_tile_vs_oracle_rel_rmse": rel_rmse}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--width", type=int, default=1920)
-    ap.add_argument("--height", type=int, default=1080)
-    ap.add_argument("--subdiv", type=int, default=8, help="icosphere subdivisions (8 -> 1 310 720 triangles)")
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--gaa", type=int, default=8, help="geometry samples per pixel (geometryAAModifier)")
+    ap.add_argument("--maa", type=int, default=8, help="material samples per geometry sample (materialAAModifier)")
+    ap.add_argument("--subdiv", type=int, default=8, help="icosphere subdivisions of the blob (8 -> 1 310 720 triangles)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-frame", action="store_true", help="skip the path-traced frame (configs[2]) reported beside the headline value")
+    ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported beside the headline value")
+    ap.add_argument("--no-c5", action="store_true", help="skip the 49.8 M-triangle configuration (about 40 s of scene set-up)")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--profile-tag", default="r02", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
     args = ap.parse_args()
 
     import torch
@@ -104,8 +373,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback for the ray-tracing path)")
-    # RTGPU_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks share
-    # devices, collectives run on host copies); the measured configuration is always nccl = RCCL
+    # RTGPU_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs than ranks (ranks share devices,
+    # collectives run on host copies, the frame is gathered with torch.distributed); the measured configuration is
+    # always nccl = RCCL with the library's own gather
     backend = os.environ.get("RTGPU_BENCH_BACKEND", "nccl")
     if backend != "nccl":
         local_rank %= torch.cuda.device_count()
@@ -117,150 +387,64 @@ def main():
         else:
             dist.init_process_group(backend)
     api.set_device(local_rank)
+    args.backend = backend
 
-    def all_reduce(t, op):
-        if backend == "nccl":
-            dist.all_reduce(t, op=op)
-        else:
-            h = t.cpu()
-            dist.all_reduce(h, op=op)
-            t.copy_(h)
-
-    W, H = args.width, args.height
-    sc, cam_m, yfov = scenes.blob_scene(args.subdiv)
-    ntri = sc.n_triangles()
-    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
-    scene = api.Scene(sc)
-    info = scene.info()
-
-    n = W * H
-    # rank 0 traces pixel-centre rays, other ranks jittered ones (different sample of the same frame)
-    st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, seed=rank,
-                           jitter_mode=abi.JITTER_CENTER if rank == 0 else abi.JITTER_RANDOM)
-    d_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    d_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
-    d_hits = torch.empty((n, 5), dtype=torch.int32, device=dev)  # rtgpu_hit = 5 dwords
-    stream = torch.cuda.current_stream()
-    api.generate_primary_device(cam, st, 0, d_o, d_d, stream)
-    torch.cuda.synchronize()
-
-    # per-ray work counters (boxes / triangles a ray tests when it is traversed on its own: the
-    # figure the algorithmic byte count is defined on; the timed kernel's cooperative schedule
-    # tests some more)
-    d_cnt = torch.zeros((n, 2), dtype=torch.int32, device=dev)
-    scene.trace_counts_device(d_o, d_d, n, d_cnt, stream)
-    torch.cuda.synchronize()
-    cnt = d_cnt.to(torch.float64).mean(dim=0).tolist()
-    n_nodes, n_tris = cnt[0], cnt[1]
-
-    for _ in range(args.warmup):
-        scene.trace_rays_device(d_o, d_d, n, d_hits, stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
-    t0 = time.perf_counter()
-    ev[0].record(stream)
-    for k in range(args.steps):
-        scene.trace_rays_device(d_o, d_d, n, d_hits, stream)
-        ev[k + 1].record(stream)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        all_reduce(tt, dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
-    kernel_ms = [ev[k].elapsed_time(ev[k + 1]) for k in range(args.steps)]
-    kernel_ms_avg = float(np.mean(kernel_ms))
-    hits = d_hits.cpu().numpy().view(np.uint32)
-    hit_frac = float((hits[:, 2] != 0xFFFFFFFF).mean())
-
-    total_rays = float(n) * args.steps * world
-    mrays = total_rays / elapsed / 1e6
-    # algorithmic bytes per ray: ray in 32 B, hit out 16 B, 32 B per tree-node box record and
-    # 36 B per triangle tested
-    bytes_per_ray = 32.0 + 16.0 + 32.0 * n_nodes + 36.0 * n_tris
-    achieved = bytes_per_ray * n / (kernel_ms_avg * 1e-3) / 1e9
-    traffic = None
-    tpath = os.path.join(HERE, "profiles", "traffic_trace_closest.json")
-    if os.path.exists(tpath):
-        try:
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    # VALU wave-instructions per launch from the committed PMC pass (SQ_INSTS_VALU): each occupies a SIMD's issue port
-    # for 4 cycles (wave64 on a 16-lane SIMD); 256 CUs x 4 SIMDs at 2.4 GHz
-    valu_issue = None
-    ppath = os.path.join(HERE, "profiles", "r01f_pmc_summary.json")
-    if os.path.exists(ppath) and (args.width, args.height, args.subdiv) == (1920, 1080, 8):
-        try:
-            valu = json.load(open(ppath))["per_launch"]["SQ_INSTS_VALU"]["mean"]
-            valu_issue = valu * 4.0 / 1024.0 / (kernel_ms_avg * 1e-3 * 2.4e9)
-        except Exception:
-            valu_issue = None
-
+    res = bench_headline(args, torch, dist, api, abi, scenes, rank, world, dev)
+    st, info = res["st"], res["info"]
+    mrays = res["rays"] / res["elapsed"] / 1e6
     out = {
         "metric": "Mrays/s (primary+secondary) and ms/frame at fixed spp, 1/2/4/8 MI355X",
         "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+        "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "configs[1]: fractal-displaced icosphere, %d triangles, %dx%d primary rays (1 per pixel), "
-                               "closest hit on one MI355X per rank" % (ntri, W, H),
-                   "rays_per_step_per_gpu": n, "hit_fraction": hit_frac, "tree_nodes": int(info.n_nodes),
-                   "tree_max_depth": int(info.max_depth), "scene_build_ms": float(info.build_ms),
-                   "scene_hbm_bytes": int(info.device_bytes)},
-        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                     "kernel": "trace_closest_steal_kernel<false>", "kernel_ms_avg": kernel_ms_avg,
-                     "bytes_per_ray": bytes_per_ray, "nodes_per_ray": n_nodes, "tris_per_ray": n_tris,
-                     # the tree and triangles (scene_hbm_bytes) fit the 256 MiB Infinity Cache, so most of the
-                     # algorithmic bytes never reach HBM: the measured HBM rate is reported beside the algorithmic one
-                     "hbm_measured_GBps": (traffic / (kernel_ms_avg * 1e-3) / 1e9) if traffic else None,
-                     # what actually binds this kernel: the share of the VALU issue slots (at 2.4 GHz) its instructions take
-                     "valu_issue_frac": valu_issue},
+        "config": {"workload": "north-star: path-traced frame of the blob-in-a-room scene (%d triangles, diffuse + glossy, area + point light), "
+                               "%dx%d, %dx%d = %d spp, path length 9; %dx%d squares interleaved over %d GPU(s), gathered on rank 0"
+                               % (res["scene"].n_triangles(), st.width, st.height, st.geometry_aa, st.material_aa, st.geometry_aa * st.material_aa,
+                                  TILE, TILE, world),
+                   "rays_per_frame": res["rays"] / args.steps, "ms_per_frame": res["elapsed"] / args.steps * 1e3,
+                   "tree_nodes": int(info.n_nodes), "tree_max_depth": int(info.max_depth), "scene_build_ms": float(info.build_ms),
+                   "scene_hbm_bytes": int(info.device_bytes), "gather": res["gather"], **res["checks"]},
     }
-
-    if not args.no_frame:
-        try:
-            out["frame"] = bench_frame(torch, dist, dev, rank, world, all_reduce)
-        except Exception as e:  # noqa: BLE001  (the headline line above must still be printed)
-            out["frame"] = {"error": "%s: %s" % (type(e).__name__, e)}
-
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        import oracle
-        threads = oracle.default_threads()
-        t0 = time.perf_counter()
-        osc = oracle.OracleScene(sc, threads=threads)
-        build_s = time.perf_counter() - t0
-        o_h = d_o.cpu().numpy()
-        d_h = d_d.cpu().numpy()
-        reps, spent = 0, 0.0
-        while spent < 12.0 and reps < 2000:
-            t0 = time.perf_counter()
-            ref = osc.trace_closest(o_h, d_h, threads=threads)
-            spent += time.perf_counter() - t0
-            reps += 1
-        same = (ref["inst"] == hits[:, 2]) & (ref["prim"] == hits[:, 1])
-        # rays whose ids differ must be exact ties in t (two triangles at the bit-identical distance)
-        bad = np.nonzero(~same)[0][:64]
-        ties = 0
-        if bad.size:
-            br, tied = osc.brute_closest(o_h[bad], d_h[bad])
-            ties = int(((tied >= 2) & (br["prim"] == hits[bad, 1])).sum())
-        out["cpu_baseline"] = {"value": n * reps / spent / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
-                               "sample": "the same %d primary rays, %d passes of the CPU oracle (%.1f s), tree build %.1f s excluded"
-                                         % (n, reps, spent, build_s),
-                               "id_mismatches_vs_gpu": int((~same).sum()), "of_which_exact_t_ties": ties}
+    if rank == 0 and world == 1:
+        if not args.no_roofline:
+            rl, stages = frame_rooflines(torch, api, abi, res["handle"], res["cam"], st, dev, info, "trace_stage_kernel<kTraceSingle>")
+            counters, src = committed_counters(args.profile_tag)
+            if counters and "headline_trace_stage" in counters:
+                c = counters["headline_trace_stage"]
+                rl["traffic"] = c.get("hbm_bytes_per_frame")
+                rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
+            out["roofline"] = rl
+            out["stages_one_batch_in_flight"] = stages
+        if not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(res, abi, api, torch, dev)
+            except Exception as e:  # noqa: BLE001
+                out["cpu_baseline"] = {"error": "%s: %s" % (type(e).__name__, e)}
+    res["handle"].close()
+    res["frame"] = None
+    if rank == 0 and world == 1 and not args.no_extras:
+        extras = {}
+        steps = [("configs[1]", lambda: bench_c2(args, torch, api, abi, scenes, dev)),
+                 ("configs[2]", lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 1920, 1080, 8, 8, dev,
+                                                    "configs[2]: interior scene, %d triangles, 1920x1080, 8x8 spp, path length 9",
+                                                    "trace_stage_kernel<kTraceSingle>"))]
+        if not args.no_c5:
+            steps.append(("configs[4]", lambda: bench_frame(torch, api, abi, *scenes.cluster_scene(38, args.subdiv, flatten=True), 1920, 1080, 4, 4, dev,
+                                                            "configs[4]: 38 copies of the blob flattened into one mesh, %d triangles, camera inside the cluster, "
+                                                            "diffuse, 1920x1080, 4x4 = 16 spp, path length 9", "trace_stage_kernel<kTraceSingle>", frames=2)))
+        for name, fn in steps:
+            try:
+                extras[name] = fn()
+            except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
+                extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
+        out["extras"] = extras
     if rank == 0:
         print(json.dumps(out))
+        sys.stdout.flush()
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+        os._exit(0)   # a helper thread stuck in a communicator rendezvous must not keep the process alive
 
 
 if __name__ == "__main__":

@@ -43,8 +43,9 @@ typedef enum rtgpu_status {
     RTGPU_ERR_LIMIT = 6,            /* a documented size limit of an entry point was exceeded */
     RTGPU_ERR_IO = 7,               /* std::runtime_error("Failed to load gltf") io/GLTF.cpp:676-678 and the loader's other
                                      * complaints about a file's content */
-    RTGPU_ERR_UNSUPPORTED = 8       /* std::runtime_error("Unsupported ...") of the loader (io/GLTF.cpp:62,82,91,204,233), and
+    RTGPU_ERR_UNSUPPORTED = 8,      /* std::runtime_error("Unsupported ...") of the loader (io/GLTF.cpp:62,82,91,204,233), and
                                      * file features this library has no decoder for (JPEG, HDR maps) */
+    RTGPU_ERR_COMM = 9              /* RCCL could not be loaded or one of its calls failed (multi-GPU rendering) */
 } rtgpu_status;
 
 /* ---- scene description (flat arrays; replaces the DynamicScene graph) ---------------- */
@@ -208,7 +209,9 @@ typedef struct rtgpu_render_settings {
     int32_t max_path_length;                     /* reference hard-codes 10, renderer/Renderer.cpp:130 */
     uint32_t seed;                               /* key of the counter-based RNG */
     int32_t jitter_mode;                         /* rtgpu_jitter_mode */
-    int32_t reserved;
+    int32_t n_gpus;                              /* rtgpu_render only: 0 or 1 = the scene's device; G > 1 = the frame's tile is cut into
+                                                  * squares shared out over G devices of this process and gathered with RCCL (what the
+                                                  * reference does with one process per tile and --mergetiles, exe/Raytracer.cpp:260-277) */
 } rtgpu_render_settings;
 
 typedef struct rtgpu_render_stats {
@@ -269,6 +272,66 @@ int rtgpu_render(const rtgpu_scene* scene, const rtgpu_camera* camera,
 int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera,
                         const rtgpu_render_settings* settings, float* d_rgb_out,
                         rtgpu_render_stats* stats, void* hip_stream);
+
+/* ---- one frame over several GPUs ------------------------------------------------------------
+ *
+ * The reference's scale-out is one process per tile (--xstart/--xend/--ystart/--yend, exe/Raytracer.cpp:65-68) whose
+ * TILE files (io/TileFile.cpp:8-27) a last run pastes together (--mergetiles, exe/Raytracer.cpp:260-277,
+ * io/TileFile.cpp:29-70).  Here the settings' tile is cut into tile_size x tile_size squares numbered row by row; square k
+ * belongs to rank k % world; a rank's squares lie one after the other in its compact buffer (3 floats per pixel, each
+ * square row by row, squares that stick out of the tile padded with zeros); the buffers meet on rank 0 through RCCL
+ * send / receive pairs and a kernel writes them into FrameBuffer order.  A pixel's random numbers depend on its position in
+ * the frame only: the frame is bit-identical for every world size.
+ *
+ * rtgpu_render with settings->n_gpus > 1 does all of this inside one process.  The entry points below are for hosts that
+ * run one process per GPU: rank 0 makes an id, the host program hands it to the other processes, every process makes its
+ * communicator on its own device (rtgpu_set_device first), renders its squares and joins the gather. */
+#define RTGPU_COMM_ID_BYTES 128
+typedef struct rtgpu_comm rtgpu_comm;
+int rtgpu_comm_unique_id(uint8_t id[RTGPU_COMM_ID_BYTES]);
+/* Blocks until all `world` ranks have called it with the same id. */
+int rtgpu_comm_create(const uint8_t id[RTGPU_COMM_ID_BYTES], int rank, int world, rtgpu_comm** out);
+void rtgpu_comm_destroy(rtgpu_comm* comm);
+/* Floats in the compact buffer of `rank` (0 on bad arguments). */
+uint64_t rtgpu_tile_buffer_floats(const rtgpu_render_settings* settings, int tile_size, int rank, int world);
+/* Renderer::render for the squares of `rank` into its compact device buffer; returns when the work is complete. */
+int rtgpu_render_tiles_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                              int tile_size, int rank, int world, float* d_tiles, rtgpu_render_stats* stats, void* hip_stream);
+/* Enqueues the gather on hip_stream: ranks > 0 send d_tiles, rank 0 receives and writes the tile's pixels of d_frame
+ * (width * height * 3 floats on rank 0's device; ignored elsewhere).  Every rank of the communicator must call. */
+int rtgpu_gather_tiles_device(rtgpu_comm* comm, const rtgpu_render_settings* settings, int tile_size,
+                              const float* d_tiles, float* d_frame, void* hip_stream);
+/* The last step of the gather alone: d_all_tiles holds the `world` compact buffers one after the other, each at a multiple of
+ * rtgpu_tile_buffer_floats(.., rank 0, world) floats (how rank 0 lays them out).  For checking the square order on one GPU. */
+int rtgpu_scatter_tiles_device(const rtgpu_render_settings* settings, int tile_size, int world, const float* d_all_tiles,
+                               float* d_frame, void* hip_stream);
+/* A copy of a built scene on another device of this process (device-to-device; no rebuild). */
+int rtgpu_scene_replicate(const rtgpu_scene* src, int device, rtgpu_scene** out);
+
+/* Work counters of a render, for the roofline model of the integrator's traversal stages: the frame is rendered with every ray
+ * traversed on its own by one lane (nearer child first, pruned by its own hits; the reference's counterpart is BVHDiag,
+ * shape/bvh/BVHNode.h:11-15, summed into the --perffci image) and the child boxes / triangles tested are added up per class of
+ * ray.  The image is the one rtgpu_render_device writes. */
+typedef struct rtgpu_render_work {
+    uint64_t extension_rays, extension_boxes, extension_triangles;
+    uint64_t shadow_rays, shadow_boxes, shadow_triangles;
+    uint64_t primary_rays, primary_boxes, primary_triangles;
+} rtgpu_render_work;
+int rtgpu_render_work_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                             float* d_rgb_out, rtgpu_render_work* work, void* hip_stream);
+
+/* Device time of a render by stage (HIP events around every kernel launch, one batch of paths in flight at a time so that
+ * launches do not overlap): what the reference prints as one number, "Rendering time" (exe/Raytracer.cpp:339-341), split the
+ * way the wavefront pipeline is.  A stage's average launch duration is its ms / launches.  The image is the one
+ * rtgpu_render_device writes; the call itself is slower than rtgpu_render_device (no overlap of batches). */
+typedef struct rtgpu_render_profile {
+    double primary_ms, shade_ms, trace_ms, gather_ms, resolve_ms;
+    double total_ms;
+    uint32_t primary_launches, shade_launches, trace_launches, gather_launches, resolve_launches;
+    uint32_t reserved;
+} rtgpu_render_profile;
+int rtgpu_render_profile_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                                float* d_rgb_out, rtgpu_render_profile* profile, void* hip_stream);
 
 /* PerspectiveCamera(fov) + setTransform (camera/PerspectiveCamera.cpp:7-19): fills *out from a
  * horizontal field of view in degrees and a row-major object->world 4x4. */

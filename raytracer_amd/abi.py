@@ -101,7 +101,18 @@ class RenderSettings(C.Structure):
     _fields_ = [("width", C.c_int32), ("height", C.c_int32),
                 ("x_start", C.c_int32), ("y_start", C.c_int32), ("x_end", C.c_int32), ("y_end", C.c_int32),
                 ("geometry_aa", C.c_int32), ("material_aa", C.c_int32), ("max_path_length", C.c_int32),
-                ("seed", C.c_uint32), ("jitter_mode", C.c_int32), ("reserved", C.c_int32)]
+                ("seed", C.c_uint32), ("jitter_mode", C.c_int32), ("n_gpus", C.c_int32)]
+
+
+class RenderWork(C.Structure):
+    _fields_ = [(n, C.c_uint64) for n in ("extension_rays", "extension_boxes", "extension_triangles",
+                                          "shadow_rays", "shadow_boxes", "shadow_triangles",
+                                          "primary_rays", "primary_boxes", "primary_triangles")]
+
+
+class RenderProfile(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("primary_ms", "shade_ms", "trace_ms", "gather_ms", "resolve_ms", "total_ms")] + \
+               [(n, C.c_uint32) for n in ("primary_launches", "shade_launches", "trace_launches", "gather_launches", "resolve_launches", "reserved")]
 
 
 class RenderStats(C.Structure):

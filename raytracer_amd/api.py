@@ -29,6 +29,8 @@ EXPORTS = [
     "rtgpu_gltf_load", "rtgpu_gltf_set_workdir", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
     "rtgpu_write_exr", "rtgpu_write_png",
     "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
+    "rtgpu_comm_unique_id", "rtgpu_comm_create", "rtgpu_comm_destroy", "rtgpu_tile_buffer_floats", "rtgpu_render_tiles_device",
+    "rtgpu_gather_tiles_device", "rtgpu_scatter_tiles_device", "rtgpu_scene_replicate", "rtgpu_render_work_device", "rtgpu_render_profile_device",
 ]
 
 _lib = None
@@ -80,6 +82,19 @@ def lib():
     L.rtgpu_scene_gather_photons.argtypes = [vp, fp, fp, C.c_uint64, vp]
     L.rtgpu_write_exr.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_int]
     L.rtgpu_write_png.argtypes = [C.c_char_p, fp, C.c_int32, C.c_int32, C.c_double, C.c_double]
+    L.rtgpu_comm_unique_id.argtypes = [vp]
+    L.rtgpu_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.rtgpu_comm_destroy.argtypes = [vp]
+    L.rtgpu_comm_destroy.restype = None
+    L.rtgpu_tile_buffer_floats.argtypes = [C.POINTER(abi.RenderSettings), C.c_int, C.c_int, C.c_int]
+    L.rtgpu_tile_buffer_floats.restype = C.c_uint64
+    L.rtgpu_render_tiles_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int, C.c_int, C.c_int, vp,
+                                            C.POINTER(abi.RenderStats), vp]
+    L.rtgpu_gather_tiles_device.argtypes = [vp, C.POINTER(abi.RenderSettings), C.c_int, vp, vp, vp]
+    L.rtgpu_scatter_tiles_device.argtypes = [C.POINTER(abi.RenderSettings), C.c_int, C.c_int, vp, vp, vp]
+    L.rtgpu_scene_replicate.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.rtgpu_render_profile_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp, C.POINTER(abi.RenderProfile), vp]
+    L.rtgpu_render_work_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp, C.POINTER(abi.RenderWork), vp]
     _lib = L
     return L
 
@@ -142,9 +157,12 @@ def _stream_ptr(stream):
 class Scene:
     """A built, GPU-resident scene (the reference's Scene after DynamicScene::build)."""
 
-    def __init__(self, scene):
+    def __init__(self, scene, _handle=None):
         """scene: abi.SceneData, or an abi.SceneDesc whose arrays the caller keeps alive during this call
         (e.g. gltf.GltfScene.desc)."""
+        if _handle is not None:
+            self._h = _handle
+            return
         h = C.c_void_p()
         if isinstance(scene, abi.SceneDesc):
             _check(lib().rtgpu_scene_create(C.byref(scene), C.byref(h)))
@@ -173,6 +191,12 @@ class Scene:
     @property
     def handle(self):
         return self._h
+
+    def replicate(self, device: int) -> "Scene":
+        """A copy of this built scene on another device of the process (device-to-device, no rebuild)."""
+        h = C.c_void_p()
+        _check(lib().rtgpu_scene_replicate(self._h, int(device), C.byref(h)))
+        return Scene(None, _handle=h)
 
     def info(self) -> abi.SceneInfo:
         out = abi.SceneInfo()
@@ -267,3 +291,67 @@ class Renderer:
         stats = abi.RenderStats()
         _check(lib().rtgpu_render_device(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), C.byref(stats), _stream_ptr(stream)))
         return stats
+
+    def render_work_device(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, d_framebuffer, stream=None) -> abi.RenderWork:
+        """The same frame with every ray traversed on its own and its boxes / triangles counted (roofline model input)."""
+        work = abi.RenderWork()
+        _check(lib().rtgpu_render_work_device(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), C.byref(work), _stream_ptr(stream)))
+        return work
+
+    def render_profile_device(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, d_framebuffer, stream=None) -> abi.RenderProfile:
+        """The same frame, one batch at a time with HIP events around every launch: device time per stage."""
+        prof = abi.RenderProfile()
+        _check(lib().rtgpu_render_profile_device(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), C.byref(prof), _stream_ptr(stream)))
+        return prof
+
+    def render_tiles_device(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, tile_size, rank, world, d_tiles, stream=None):
+        """This rank's squares of the frame into its compact device buffer (see raytracer_amd.distributed)."""
+        stats = abi.RenderStats()
+        _check(lib().rtgpu_render_tiles_device(scene.handle, C.byref(cam), C.byref(settings), int(tile_size), int(rank), int(world),
+                                               _ptr(d_tiles), C.byref(stats), _stream_ptr(stream)))
+        return stats
+
+
+def tile_buffer_floats(settings: abi.RenderSettings, tile_size, rank, world) -> int:
+    return int(lib().rtgpu_tile_buffer_floats(C.byref(settings), int(tile_size), int(rank), int(world)))
+
+
+def scatter_tiles_device(settings: abi.RenderSettings, tile_size, world, d_all_tiles, d_frame, stream=None):
+    _check(lib().rtgpu_scatter_tiles_device(C.byref(settings), int(tile_size), int(world), _ptr(d_all_tiles), _ptr(d_frame), _stream_ptr(stream)))
+
+
+COMM_ID_BYTES = 128
+
+
+def comm_unique_id() -> bytes:
+    """The id rank 0 makes and the host program hands to the other ranks (ncclGetUniqueId)."""
+    buf = (C.c_uint8 * COMM_ID_BYTES)()
+    _check(lib().rtgpu_comm_unique_id(buf))
+    return bytes(buf)
+
+
+class Comm:
+    """One rank's communicator of the frame gather (RCCL), on the device current when it is made."""
+
+    def __init__(self, unique_id: bytes, rank: int, world: int):
+        if len(unique_id) != COMM_ID_BYTES:
+            raise ValueError("communicator id must be %d bytes" % COMM_ID_BYTES)
+        h = C.c_void_p()
+        buf = (C.c_uint8 * COMM_ID_BYTES).from_buffer_copy(unique_id)
+        _check(lib().rtgpu_comm_create(buf, int(rank), int(world), C.byref(h)))
+        self._h, self.rank, self.world = h, int(rank), int(world)
+
+    def gather_tiles_device(self, settings: abi.RenderSettings, tile_size, d_tiles, d_frame, stream=None):
+        _check(lib().rtgpu_gather_tiles_device(self._h, C.byref(settings), int(tile_size), _ptr(d_tiles),
+                                               _ptr(d_frame) if d_frame is not None else C.c_void_p(0), _stream_ptr(stream)))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            lib().rtgpu_comm_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -67,14 +67,15 @@ void xf_vector(const double* M, const float p[3], float out[3])
 
 bool affine(const double* m) { return m[12] == 0.0 && m[13] == 0.0 && m[14] == 0.0 && m[15] == 1.0; }
 
-template <typename T>
-int upload(const std::vector<T>& v, const T** out, uint64_t& bytes)
+// Copies a host array to the scene's device and hangs it on the SceneView member (registered with its size, so that the
+// scene can be copied to another device later).
+template <typename M, typename T>
+int upload(rtgpu_scene& sc, const M* rt::SceneView::*member, const std::vector<T>& v, uint64_t& bytes)
 {
-    *out = nullptr;
     if (v.empty()) return RTGPU_OK;
     void* p = nullptr;
     RT_HIP(hipMalloc(&p, v.size() * sizeof(T)));
-    *out = (const T*)p;
+    sc.set_array(member, (const M*)p, v.size() * sizeof(T));
     bytes += v.size() * sizeof(T);
     RT_HIP(hipMemcpy(p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice));
     return RTGPU_OK;
@@ -207,6 +208,11 @@ int set_error(int code, const std::string& msg) { return fail(code, msg); }
 void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
+    rt::destroy_multi(multi);
+    multi = nullptr;
+    rt::destroy_render_cache(renderCache);
+    renderCache = nullptr;
+    arrays.clear();
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
                           view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.envMap, view.kdPos, view.kdNormal, view.kdEnergy};
     for (const void* p : ptrs)
@@ -546,17 +552,14 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v = SceneView{};
     uint64_t bytes = 0;
     int rc;
-    const float4* p4;
-    if ((rc = upload(nodes, (const Node64**)&p4, bytes))) { sc->release(); delete sc; return rc; }
-    v.nodes = p4;
-    if ((rc = upload(tris, (const TriRec**)&p4, bytes))) { sc->release(); delete sc; return rc; }
-    v.tris = p4;
-    if ((rc = upload(triIds, &v.triIds, bytes)) || (rc = upload(inst, &v.inst, bytes)) || (rc = upload(instOrder, &v.instOrder, bytes)) ||
-        (rc = upload(vertNormals, &v.vertNormals, bytes)) || (rc = upload(triMat, &v.triMaterial, bytes)) ||
-        (rc = upload(mats, &v.materials, bytes)) || (rc = upload(pls, &v.pointLights, bytes)) ||
-        (rc = upload(als, &v.areaLights, bytes)) || (rc = upload(dls, &v.dirLights, bytes)) ||
-        (rc = upload(vertUV, &v.vertUV, bytes)) || (rc = upload(texs, &v.textures, bytes)) || (rc = upload(texels, &v.texels, bytes)) ||
-        (rc = upload(instFwd, &v.instFwd, bytes)) || (rc = upload(envTexels, &v.envMap, bytes))) {
+    using SV = SceneView;
+    if ((rc = upload(*sc, &SV::nodes, nodes, bytes)) || (rc = upload(*sc, &SV::tris, tris, bytes)) ||
+        (rc = upload(*sc, &SV::triIds, triIds, bytes)) || (rc = upload(*sc, &SV::inst, inst, bytes)) || (rc = upload(*sc, &SV::instOrder, instOrder, bytes)) ||
+        (rc = upload(*sc, &SV::vertNormals, vertNormals, bytes)) || (rc = upload(*sc, &SV::triMaterial, triMat, bytes)) ||
+        (rc = upload(*sc, &SV::materials, mats, bytes)) || (rc = upload(*sc, &SV::pointLights, pls, bytes)) ||
+        (rc = upload(*sc, &SV::areaLights, als, bytes)) || (rc = upload(*sc, &SV::dirLights, dls, bytes)) ||
+        (rc = upload(*sc, &SV::vertUV, vertUV, bytes)) || (rc = upload(*sc, &SV::textures, texs, bytes)) || (rc = upload(*sc, &SV::texels, texels, bytes)) ||
+        (rc = upload(*sc, &SV::instFwd, instFwd, bytes)) || (rc = upload(*sc, &SV::envMap, envTexels, bytes))) {
         sc->release();
         delete sc;
         return rc;
@@ -713,6 +716,7 @@ static int check_settings(const rtgpu_render_settings* st)
     if (st->max_path_length > 64) return fail(RTGPU_ERR_LIMIT, "max_path_length exceeds 64");
     if (st->jitter_mode != RTGPU_JITTER_RANDOM && st->jitter_mode != RTGPU_JITTER_CENTER)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown jitter mode");
+    if (st->n_gpus < 0 || st->n_gpus > 64) return fail(RTGPU_ERR_INVALID_ARGUMENT, "n_gpus out of range");
     return RTGPU_OK;
 }
 
@@ -739,11 +743,54 @@ int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera, co
     if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
     if (!d_rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
+    if (settings->n_gpus > 1) return fail(RTGPU_ERR_INVALID_ARGUMENT, "n_gpus > 1 needs rtgpu_render or the tile entry points");
     RT_HIP(hipSetDevice(scene->device));
     return rt::guarded([&]() -> int {
         std::string err;
-        hipError_t e = rt::render_wavefront(*scene, *camera, *settings, d_rgb_out, stats, (hipStream_t)hip_stream, err);
+        hipError_t e = rt::render_wavefront(*scene, *camera, *settings, nullptr, d_rgb_out, stats, nullptr, (hipStream_t)hip_stream, err);
         if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+        return RTGPU_OK;
+    });
+}
+
+int rtgpu_render_profile_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                                float* d_rgb_out, rtgpu_render_profile* profile, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
+    if (!d_rgb_out || !profile) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null frame buffer / profile record");
+    if (settings->n_gpus > 1) return fail(RTGPU_ERR_INVALID_ARGUMENT, "the profiling render runs on one device");
+    RT_HIP(hipSetDevice(scene->device));
+    return rt::guarded([&]() -> int {
+        std::string err;
+        hipError_t e = rt::render_wavefront(*scene, *camera, *settings, nullptr, d_rgb_out, nullptr, nullptr, (hipStream_t)hip_stream, err, profile);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+        return RTGPU_OK;
+    });
+}
+
+int rtgpu_render_work_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                             float* d_rgb_out, rtgpu_render_work* work, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
+    if (!d_rgb_out || !work) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null frame buffer / work record");
+    if (settings->n_gpus > 1) return fail(RTGPU_ERR_INVALID_ARGUMENT, "the counting render runs on one device");
+    RT_HIP(hipSetDevice(scene->device));
+    return rt::guarded([&]() -> int {
+        std::string err;
+        uint64_t w[9];
+        hipError_t e = rt::render_wavefront(*scene, *camera, *settings, nullptr, d_rgb_out, nullptr, w, (hipStream_t)hip_stream, err);
+        if (e != hipSuccess) return fail(e == hipErrorOutOfMemory ? RTGPU_ERR_OUT_OF_MEMORY : RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+        work->extension_rays = w[0]; work->extension_boxes = w[1]; work->extension_triangles = w[2];
+        work->shadow_rays = w[3]; work->shadow_boxes = w[4]; work->shadow_triangles = w[5];
+        work->primary_rays = w[6]; work->primary_boxes = w[7]; work->primary_triangles = w[8];
         return RTGPU_OK;
     });
 }
@@ -756,6 +803,14 @@ int rtgpu_render(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtg
     if (int rc = check_settings(settings)) return rc;
     if (!rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
     RT_HIP(hipSetDevice(scene->device));
+    if (settings->n_gpus > 1) {
+        if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+            return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
+        if (progress) progress("Rendering tiles", 0.0f, 0, user);
+        if (int rc = rt::render_multi_entry(*scene, *camera, *settings, rgb_out, stats)) return rc;
+        if (progress) progress("Rendering tiles", 1.0f, 1, user);
+        return RTGPU_OK;
+    }
     const size_t bytes = (size_t)settings->width * settings->height * 3 * sizeof(float);
     DevBuf fb;
     RT_HIP(hipMalloc(&fb.p, bytes));

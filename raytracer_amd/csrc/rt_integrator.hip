@@ -33,6 +33,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 #include <thread>
 #include <vector>
@@ -114,15 +115,33 @@ __device__ __forceinline__ float4 f4(float x, float y, float z, float w)
 }
 
 struct Batch {
-    uint32_t pixelStart;  // first tile-local pixel index of the batch
+    uint32_t pixelStart;  // first pixel of the batch, counted in the call's pixel order
     uint32_t nPixels;
+    // Pixel order of the call.  tileSize == 0: the settings' tile row by row, results go to the frame buffer.
+    // tileSize = T > 0: the settings' tile is cut into T x T squares, square k (row by row) belongs to rank k % nRanks,
+    // a rank walks its squares in order and each square row by row; results go to a compact buffer in that order
+    // (squares that stick out of the tile keep their full T x T slots, the outside pixels are written as zeros).
+    uint32_t tileSize, nRanks, rank, tilesX, nTiles;
 };
 
-__device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, uint32_t tileIdx, int& x, int& y)
+// Position `idx` of the call's pixel order -> pixel (x, y).  Returns the pixel's index in the frame buffer (the key
+// of its random numbers, so an image does not depend on how it was cut); `valid` is false for the padding of a square
+// that sticks out of the tile and for squares behind the last one.
+__device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, const Batch& b, uint32_t idx, int& x, int& y, bool& valid)
 {
-    const uint32_t tw = (uint32_t)(st.x_end - st.x_start);
-    x = st.x_start + (int)(tileIdx % tw);
-    y = st.y_start + (int)(tileIdx / tw);
+    if (b.tileSize == 0u) {
+        const uint32_t tw = (uint32_t)(st.x_end - st.x_start);
+        x = st.x_start + (int)(idx % tw);
+        y = st.y_start + (int)(idx / tw);
+        valid = true;
+    } else {
+        const uint32_t T = b.tileSize, tt = T * T;
+        const uint32_t j = idx / tt, w = idx % tt;
+        const uint32_t k = j * b.nRanks + b.rank;
+        x = st.x_start + (int)((k % b.tilesX) * T + w % T);
+        y = st.y_start + (int)((k / b.tilesX) * T + w / T);
+        valid = k < b.nTiles && x < st.x_end && y < st.y_end;
+    }
     return (uint32_t)(y * st.width + x);
 }
 
@@ -179,15 +198,23 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     const int lane = threadIdx.x;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint32_t s0 = blockIdx.x * 64u + lane;
-    const bool has = s0 < batch.nPixels * G;
-    const uint32_t s = has ? s0 : 0u;
+    const bool inBatch = s0 < batch.nPixels * G;
+    const uint32_t s = inBatch ? s0 : 0u;
     const uint32_t pl = s / G, i = s % G;
     int x, y;
-    tile_pixel(st, batch.pixelStart + pl, x, y);
+    bool valid;
+    tile_pixel(st, batch, batch.pixelStart + pl, x, y, valid);
+    const bool has = inBatch && valid;
     F3 o, d;
     camera_ray(cam, st, x, y, (int)i, o, d);
     const TraceResult r = wave_closest<MODE>(sv, has, o, d, lds, lane);
-    if (!has) return;
+    if (!inBatch) return;
+    if (!valid) {   // padding of the compact buffer: a black sample without paths
+        pool.sLive[s] = 0;
+        pool.sHasVar[s] = 0;
+        pool.result[(size_t)s * M] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+        return;
+    }
     const bool hit = r.inst != kInvalid;
 
     RGBf value = rgb(0, 0, 0);
@@ -229,8 +256,12 @@ constexpr int kShadeBlock = RT_SHADE_BLOCK;
 
 template <bool FIRST, bool RICH>
 __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
-                                                    const uint32_t* __restrict__ qIn, uint32_t nIn, uint32_t* __restrict__ qExt)
+                                                    const uint32_t* __restrict__ qIn, uint32_t nPaths, const uint32_t* __restrict__ cntIn,
+                                                    uint32_t* __restrict__ qExt, uint32_t* __restrict__ cnt)
 {
+    // FIRST: every path of the batch; later passes: the extension queue the previous pass filled, whose length is read
+    // here (the grid is sized from an upper bound the host knows, surplus workgroups find nothing to do)
+    const uint32_t nIn = FIRST ? nPaths : cntIn[0];
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
     uint32_t p = 0;
@@ -243,7 +274,8 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
         const uint32_t s = p / M, j = p % M;
         const uint32_t pl = s / G, i = s % G;
         int px, py;
-        const uint32_t pixel = tile_pixel(st, batch.pixelStart + pl, px, py);
+        bool pvalid;
+        const uint32_t pixel = tile_pixel(st, batch, batch.pixelStart + pl, px, py, pvalid);
         const float4 ra = FIRST ? pool.sA[s] : pool.rayA[p];
         const float4 rb = FIRST ? pool.sB[s] : pool.rayB[p];
         float4 hc;
@@ -737,15 +769,15 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             pool.result[p] = completed ? f4(total.r, total.g, total.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
         }
     }
-    queue_push2<kShadeBlock>(qExt, pool.counters + 0, pushExt, pool.qShadow, pool.counters + 1, pushShadow, p);
+    queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p);
     if (RICH) {
-        if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, pool.counters + 2, pushPhoton, p);   // uniform branch
+        if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, cnt + 2, pushPhoton, p);   // uniform branch
     }
     // Extension rays of vertices before the first variance vertex are identical for every material
     // sample j (the reference traces them once per geometry sample): count the repeats so that
     // the ray statistics only contain distinct rays.
     const unsigned long long rep = __ballot(pushExt && repeated);
-    if (rep != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)rep) - 1)) atomicAdd(pool.counters + 3, (uint32_t)__popcll(rep));
+    if (rep != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)rep) - 1)) atomicAdd(cnt + 3, (uint32_t)__popcll(rep));
 }
 
 // ---- shadow / connect and extend ------------------------------------------------------------------
@@ -786,13 +818,76 @@ __device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& po
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64, MODE == kTraceInstances ? 6 : 1) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, uint32_t nExt, uint32_t nShadow)
+__global__ __launch_bounds__(64, MODE == kTraceInstances ? 6 : 1) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, const uint32_t* __restrict__ cnt)
 {
     __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
-    const uint32_t extBlocks = (nExt + 63u) / 64u;
+    // queue lengths as the shade pass left them; the grid covers an upper bound of both
+    const uint32_t nExt = cnt[0], nShadow = cnt[1];
+    const uint32_t extBlocks = (nExt + 63u) / 64u, shadowBlocks = (nShadow + 63u) / 64u;
     if (blockIdx.x < extBlocks) extend_block<MODE>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
-    else shadow_block<MODE>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
+    else if (blockIdx.x - extBlocks < shadowBlocks) shadow_block<MODE>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
+}
+
+// The same stage with every ray traversed on its own by one lane (nearer child first, pruned by its own hits) and the
+// boxes / triangles it tests added up: work[0..2] = extension rays, boxes, triangles; work[3..5] the same for shadow
+// rays.  The figures the roofline model of the stage is defined on; results are those of the stage above.
+__device__ __forceinline__ void wave_add64(unsigned long long* dst, uint32_t v, int lane)
+{
+    unsigned long long sum = v;
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_down(sum, off, 64);
+    if (lane == 0 && sum) atomicAdd(dst, sum);
+}
+__device__ __forceinline__ TraceResult solo_closest(const SceneView& sv, F3 o, F3 d, int (*stack)[64], int lane, uint32_t& nb, uint32_t& nt)
+{
+    if (sv.singleMesh) return trace_ray<false, false, true>(sv, o, d, INFINITY, stack, lane, nb, nt);
+    if (sv.refTop) return trace_ray_reftop_closest<true>(sv, o, d, stack, lane, nb, nt);
+    return trace_ray<true, false, true>(sv, o, d, INFINITY, stack, lane, nb, nt);
+}
+__global__ __launch_bounds__(64) void trace_stage_count_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue,
+                                                               const uint32_t* __restrict__ cnt, unsigned long long* __restrict__ work)
+{
+    __shared__ int stack[kLdsStack][64];
+    const int lane = threadIdx.x;
+    const uint32_t nExt = cnt[0], nShadow = cnt[1];
+    const uint32_t extBlocks = (nExt + 63u) / 64u, shadowBlocks = (nShadow + 63u) / 64u;
+    uint32_t nb = 0, nt = 0;
+    if (blockIdx.x < extBlocks) {
+        const uint32_t q = blockIdx.x * 64u + lane;
+        const bool has = q < nExt;
+        if (has) {
+            const uint32_t p = extQueue[q];
+            const float4 ra = pool.rayA[p], rb = pool.rayB[p];
+            const TraceResult r = solo_closest(sv, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), stack, lane, nb, nt);
+            pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
+            if (!sv.singleMesh) pool.hitInst[p] = r.inst;
+        }
+        wave_add64(work + 0, has ? 1u : 0u, lane);
+        wave_add64(work + 1, nb, lane);
+        wave_add64(work + 2, nt, lane);
+    } else if (blockIdx.x - extBlocks < shadowBlocks) {
+        const uint32_t q = (blockIdx.x - extBlocks) * 64u + lane;
+        const bool has = q < nShadow;
+        if (has) {
+            const uint32_t p = pool.qShadow[q];
+            float4 ra = pool.rayA[p], rb = pool.rayB[p];
+            const bool sticky = sv.hasGlass && (__float_as_uint(rb.w) & ST_GLASS_STICKY) != 0;
+            if (sticky) { ra = pool.glassA[p]; rb = pool.glassB[p]; }
+            const F3 o = f3(ra.x, ra.y, ra.z), d = f3(rb.x, rb.y, rb.z);
+            bool occluded;
+            if (sv.singleMesh) occluded = trace_ray<false, true, true>(sv, o, d, ra.w, stack, lane, nb, nt).inst != kInvalid;
+            else if (sv.refTop) occluded = trace_ray_reftop_any(sv, o, d, ra.w, stack, lane);   // (its boxes are not counted)
+            else occluded = trace_ray<true, true, true>(sv, o, d, ra.w, stack, lane, nb, nt).inst != kInvalid;
+            if (sticky) {
+                if (occluded) pool.glassB[p] = f4(rb.x, rb.y, rb.z, __uint_as_float(kInvalid));
+            } else if (!occluded) {
+                pool.result[p] = pool.aux[p];
+            }
+        }
+        wave_add64(work + 3, has ? 1u : 0u, lane);
+        wave_add64(work + 4, nb, lane);
+        wave_add64(work + 5, nt, lane);
+    }
 }
 
 // ---- photon gather ----------------------------------------------------------------------------------
@@ -826,8 +921,9 @@ __device__ __forceinline__ void gather_path_apply(const SceneView& sv, const Poo
 }
 
 // First attempt, one lane per queued path; the paths that run out of budget go to the tail queue (counters[4]).
-__global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, Pool pool, uint32_t n)
+__global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, Pool pool, uint32_t* __restrict__ cnt)
 {
+    const uint32_t n = cnt[2];   // the grid covers an upper bound
     const uint32_t qi = blockIdx.x * 64u + threadIdx.x;
     const bool has = qi < n;
     const uint32_t p = pool.qPhoton[has ? qi : 0u];
@@ -838,15 +934,15 @@ __global__ __launch_bounds__(64) void photon_gather_stage_kernel(SceneView sv, P
     RGBf value;
     const bool finished = has && gather_photons(sv, q, dir, sv.gatherBudget, count, maxDist, value);
     if (finished) gather_path_apply(sv, pool, p, value, maxDist);
-    queue_push1<64>(pool.qPhotonTail, pool.counters + 4, has && !finished, p);
+    queue_push1<64>(pool.qPhotonTail, cnt + 4, has && !finished, p);
 }
 
 // The tail queue, one wave per path.  Launched with a fixed grid right behind the first attempt: the number of
 // queued paths is read on the device.
-__global__ __launch_bounds__(64) void photon_gather_tail_kernel(SceneView sv, Pool pool)
+__global__ __launch_bounds__(64) void photon_gather_tail_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ cnt)
 {
     __shared__ GatherWaveLds lds;
-    const uint32_t n = pool.counters[4];
+    const uint32_t n = cnt[4];
     for (uint32_t qi = blockIdx.x; qi < n; qi += gridDim.x) {
         const uint32_t p = pool.qPhotonTail[qi];
         F3 q, dir;
@@ -869,7 +965,9 @@ __global__ __launch_bounds__(256) void resolve_kernel(Pool pool, rtgpu_render_se
     if (pl >= batch.nPixels) return;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     int x, y;
-    const uint32_t pixel = tile_pixel(st, batch.pixelStart + pl, x, y);
+    bool valid;
+    uint32_t pixel = tile_pixel(st, batch, batch.pixelStart + pl, x, y, valid);
+    if (batch.tileSize != 0u) pixel = batch.pixelStart + pl;   // compact buffer: the call's pixel order
     RGBf px = rgb(0, 0, 0);
     for (uint32_t i = 0; i < G; ++i) {
         const uint32_t s = pl * G + i;
@@ -885,23 +983,214 @@ __global__ __launch_bounds__(256) void resolve_kernel(Pool pool, rtgpu_render_se
     fb[3 * (size_t)pixel] = px.r; fb[3 * (size_t)pixel + 1] = px.g; fb[3 * (size_t)pixel + 2] = px.b;
 }
 
-struct Workspace {
-    std::vector<void*> ptrs;
-    hipError_t err = hipSuccess;
-    template <typename T>
-    T* alloc(size_t n)
-    {
-        if (err != hipSuccess) return nullptr;
-        void* p = nullptr;
-        err = hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T));
-        if (err == hipSuccess) ptrs.push_back(p);
-        return (T*)p;
+// Primary rays of a batch traversed on their own, only to count their work: work[6..8] = rays, boxes, triangles.
+__global__ __launch_bounds__(64) void primary_count_kernel(SceneView sv, rtgpu_camera cam, rtgpu_render_settings st, Batch batch,
+                                                           unsigned long long* __restrict__ work)
+{
+    __shared__ int stack[kLdsStack][64];
+    const int lane = threadIdx.x;
+    const uint32_t G = (uint32_t)st.geometry_aa;
+    const uint32_t s0 = blockIdx.x * 64u + lane;
+    const bool inBatch = s0 < batch.nPixels * G;
+    const uint32_t s = inBatch ? s0 : 0u;
+    int x, y;
+    bool valid;
+    tile_pixel(st, batch, batch.pixelStart + s / G, x, y, valid);
+    uint32_t nb = 0, nt = 0;
+    const bool has = inBatch && valid;
+    if (has) {
+        F3 o, d;
+        camera_ray(cam, st, x, y, (int)(s % G), o, d);
+        (void)solo_closest(sv, o, d, stack, lane, nb, nt);
     }
-    ~Workspace()
+    wave_add64(work + 6, has ? 1u : 0u, lane);
+    wave_add64(work + 7, nb, lane);
+    wave_add64(work + 8, nt, lane);
+}
+
+constexpr int kMaxSteps = 2 * 64 + 4;       // shade passes of one batch: two per path vertex (max_path_length <= 64) and the drain
+constexpr size_t kCarveAlign = 256;
+
+// What a batch's workspace has to hold.
+struct PoolDims {
+    uint64_t P = 0, S = 0;   // paths and samples resident per batch
+    bool single = false, glass = false, add = false, photons = false, caustics = false;
+    bool operator==(const PoolDims& o) const
     {
-        for (void* p : ptrs) (void)hipFree(p);
+        return P == o.P && S == o.S && single == o.single && glass == o.glass && add == o.add && photons == o.photons && caustics == o.caustics;
     }
 };
+
+PoolDims pool_dims(const SceneView& sv, uint64_t P, uint64_t S)
+{
+    PoolDims d;
+    d.P = P; d.S = S;
+    d.single = sv.singleMesh != 0;
+    d.glass = sv.hasGlass != 0;
+    d.add = sv.hasAdd != 0;
+    d.photons = sv.pmMode != RTGPU_PM_NONE;
+    d.caustics = sv.pmMode == RTGPU_PM_CAUSTICS;
+    return d;
+}
+
+// Lays the arrays of a Pool out in one block of device memory starting at `base` (null: only the size is computed).
+// Returns the bytes needed.  The per-step counters come last: counters[step][kPoolCounters].
+size_t pool_carve(Pool& pool, char* base, const PoolDims& d)
+{
+    size_t off = 0;
+    auto take = [&](size_t bytes) -> char* {
+        char* p = base ? base + off : nullptr;
+        off += (std::max<size_t>(bytes, 1) + kCarveAlign - 1) / kCarveAlign * kCarveAlign;
+        return p;
+    };
+    const size_t P = (size_t)d.P, S = (size_t)d.S;
+    pool.rayA = (float4*)take(P * 16); pool.rayB = (float4*)take(P * 16); pool.hit = (float4*)take(P * 16);
+    pool.hitInst = (uint32_t*)take(d.single ? 4 : P * 4);
+    pool.thr = (float4*)take(P * 16); pool.aux = (float4*)take(P * 16); pool.result = (float4*)take(P * 16);
+    pool.glassN = (float4*)take(d.glass ? P * 16 : 16); pool.glassA = (float4*)take(d.glass ? P * 16 : 16); pool.glassB = (float4*)take(d.glass ? P * 16 : 16);
+    pool.acc = (float4*)take(d.add ? P * 16 : 16); pool.accPend = (float4*)take(d.add ? P * 16 : 16);
+    pool.sA = (float4*)take(S * 16); pool.sB = (float4*)take(S * 16); pool.sC = (float4*)take(S * 16);
+    pool.sLive = (uint8_t*)take(S); pool.sHasVar = (uint8_t*)take(S);
+    pool.qA = (uint32_t*)take(P * 4); pool.qB = (uint32_t*)take(P * 4); pool.qShadow = (uint32_t*)take(P * 4);
+    pool.qPhoton = (uint32_t*)take(d.photons ? P * 4 : 4);
+    pool.qPhotonTail = (uint32_t*)take(d.photons ? P * 4 : 4);
+    const size_t nC = d.caustics ? P * 16 : 16;
+    pool.cHit = (float4*)take(nC); pool.cDir = (float4*)take(nC); pool.cThrColor = (float4*)take(nC); pool.cBase = (float4*)take(nC);
+    pool.counters = (uint32_t*)take((size_t)kMaxSteps * kPoolCounters * sizeof(uint32_t));
+    return off;
+}
+
+// Events around the launches of a profiling render: spans[k] = (stage, first event, second event).
+enum Stage : int { kStagePrimary = 0, kStageShade = 1, kStageTrace = 2, kStageGather = 3, kStageResolve = 4, kStageCount = 5 };
+struct StageTimer {
+    std::vector<hipEvent_t> events;
+    size_t used = 0;
+    struct Span { int stage; size_t a, b; };
+    std::vector<Span> spans;
+    hipError_t mark(hipStream_t s, size_t& idx)
+    {
+        if (used == events.size()) {
+            hipEvent_t ev = nullptr;
+            const hipError_t e = hipEventCreate(&ev);
+            if (e != hipSuccess) return e;
+            events.push_back(ev);
+        }
+        idx = used++;
+        return hipEventRecord(events[idx], s);
+    }
+    ~StageTimer() { for (hipEvent_t ev : events) (void)hipEventDestroy(ev); }
+};
+
+// One batch in flight: a stream, its workspace, and (unless the caller must not be waited on) the pinned mirror of
+// the per-step counters with the events that say when a step's counters have arrived.
+struct LaneRun {
+    hipStream_t stream = nullptr;
+    Pool pool{};
+    uint32_t* hostCounters = nullptr;      // kMaxSteps * kPoolCounters words, pinned; null: never read back
+    hipEvent_t stepEv[4] = {nullptr, nullptr, nullptr, nullptr};
+    unsigned long long* work = nullptr;    // device, 9 counters: the counting render
+    StageTimer* timer = nullptr;           // the profiling render: events around every launch
+    uint64_t extension = 0, shadow = 0;
+};
+
+template <typename K, typename... A>
+inline void launch(K kernel, uint32_t blocks, uint32_t threads, hipStream_t s, A... args)
+{
+    hipLaunchKernelGGL(kernel, dim3(std::max(blocks, 1u)), dim3(threads), 0, s, args...);
+}
+
+// Enqueues one batch: primary, then shade / trace passes until no path is left, then resolve.
+//
+// The host never waits for the pass it has just launched.  Queue lengths live in device memory (one set of counters
+// per pass) and every kernel reads its own; a grid only needs an upper bound of its queue, and the queue of pass s is
+// at most as long as that of pass s - 1, which the host reads two passes late (by then it has long arrived).  Without a
+// pinned mirror (callers that may not synchronise) every pass runs with the bound of the first and the full number
+// of passes is enqueued.
+hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, const rtgpu_render_settings& st, const Batch& batch, float* dOut,
+                     std::string& err)
+{
+    const hipStream_t ls = ln.stream;
+    Pool& pool = ln.pool;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    const uint32_t nS = batch.nPixels * G;
+    const uint32_t nP = nS * M;
+    const int mode = trace_mode(sv);
+    const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode != RTGPU_PM_NONE;
+    static const uint32_t tailCap = std::getenv("RTGPU_GATHER_TAIL_BLOCKS") ? (uint32_t)std::atoi(std::getenv("RTGPU_GATHER_TAIL_BLOCKS")) : 16384u;
+    const int maxSteps = std::min(kMaxSteps, 2 * st.max_path_length + 2);
+    hipError_t e = hipSuccess;
+#define RB_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return e; } } while (0)
+    size_t spanA = 0, spanB = 0;
+#define TB() do { if (ln.timer) RB_TRY(ln.timer->mark(ls, spanA)); } while (0)
+#define TE(stage) do { if (ln.timer) { RB_TRY(ln.timer->mark(ls, spanB)); ln.timer->spans.push_back(StageTimer::Span{stage, spanA, spanB}); } } while (0)
+    RB_TRY(hipMemsetAsync(pool.counters, 0, (size_t)maxSteps * kPoolCounters * sizeof(uint32_t), ls));
+    TB();
+    if (mode == kTraceSingle) launch(primary_kernel<kTraceSingle>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
+    else if (mode == kTraceInstances) launch(primary_kernel<kTraceInstances>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
+    else launch(primary_kernel<kTraceLanes>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
+    TE(kStagePrimary);
+    if (ln.work) launch(primary_count_kernel, (nS + 63) / 64, 64, ls, sv, cam, st, batch, ln.work);
+    uint32_t bound = nP;           // upper bound of the number of paths the next pass shades
+    uint32_t* qIn = pool.qA;
+    uint32_t* qOut = pool.qB;
+    int steps = 0;
+    for (int step = 0; step < maxSteps; ++step) {
+        if (ln.hostCounters && step >= 2) {
+            RB_TRY(hipEventSynchronize(ln.stepEv[(step - 2) & 3]));
+            bound = ln.hostCounters[(size_t)(step - 2) * kPoolCounters];   // paths pass step - 1 shaded
+            if (bound == 0) break;
+        }
+        uint32_t* cnt = pool.counters + (size_t)step * kPoolCounters;
+        const uint32_t* cntIn = step ? cnt - kPoolCounters : cnt;
+        const uint32_t shadeBlocks = (bound + kShadeBlock - 1) / kShadeBlock;
+        TB();
+        if (rich) {
+            if (step == 0) launch(shade_kernel<true, true>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+            else launch(shade_kernel<false, true>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+        } else {
+            if (step == 0) launch(shade_kernel<true, false>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+            else launch(shade_kernel<false, false>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+        }
+        TE(kStageShade);
+        if (ln.hostCounters) {
+            RB_TRY(hipMemcpyAsync(ln.hostCounters + (size_t)step * kPoolCounters, cnt, kPoolCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+            RB_TRY(hipEventRecord(ln.stepEv[step & 3], ls));
+        }
+        if (sv.pmMode != RTGPU_PM_NONE) {
+            TB();
+            launch(photon_gather_stage_kernel, (bound + 63) / 64, 64, ls, sv, pool, cnt);
+            launch(photon_gather_tail_kernel, std::min(bound, tailCap), 64, ls, sv, pool, (const uint32_t*)cnt);
+            TE(kStageGather);
+        }
+        // extension and shadow queue are each at most `bound` long
+        const uint32_t traceBlocks = 2 * ((bound + 63) / 64);
+        TB();
+        if (ln.work) launch(trace_stage_count_kernel, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt, ln.work);
+        else if (mode == kTraceSingle) launch(trace_stage_kernel<kTraceSingle>, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt);
+        else if (mode == kTraceInstances) launch(trace_stage_kernel<kTraceInstances>, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt);
+        else launch(trace_stage_kernel<kTraceLanes>, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt);
+        TE(kStageTrace);
+        std::swap(qIn, qOut);
+        steps = step + 1;
+    }
+    TB();
+    launch(resolve_kernel, (batch.nPixels + 255) / 256, 256, ls, pool, st, batch, dOut);
+    TE(kStageResolve);
+    RB_TRY(hipGetLastError());
+    if (ln.hostCounters && steps > 0) {
+        // ray statistics: every pass's counters have arrived once the last pass's have
+        RB_TRY(hipEventSynchronize(ln.stepEv[(steps - 1) & 3]));
+        for (int s2 = 0; s2 < steps; ++s2) {
+            const uint32_t* h = ln.hostCounters + (size_t)s2 * kPoolCounters;
+            ln.extension += h[0] - h[3];
+            ln.shadow += h[1];
+        }
+    }
+#undef TB
+#undef TE
+#undef RB_TRY
+    return hipSuccess;
+}
 
 } // namespace
 
@@ -925,14 +1214,96 @@ void area_light_derived(DevAreaLight& l)
     l.area = v1Length * height / 2.0f;
 }
 
-hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st,
-                            float* dRgb, rtgpu_render_stats* stats, hipStream_t stream, std::string& err)
+// ---- host side ---------------------------------------------------------------------------------------
+// Streams, events, pinned counters and workspaces of the batches in flight are kept with the scene between calls
+// (a frame rendered as many tiles, or frame after frame, would otherwise pay about 25 allocations of up to 2 GB per
+// call); they grow when a call needs more and go when the scene does.
+struct RenderCache {
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t done = nullptr;
+        hipEvent_t stepEv[4] = {nullptr, nullptr, nullptr, nullptr};
+        uint32_t* hostCounters = nullptr;
+        void* mem = nullptr;
+        size_t bytes = 0;
+        PoolDims dims;
+        Pool pool{};
+    };
+    std::vector<Lane> lanes;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    unsigned long long* work = nullptr;   // 9 counters of the counting render
+};
+
+void destroy_render_cache(RenderCache* c)
+{
+    if (!c) return;
+    for (RenderCache::Lane& l : c->lanes) {
+        if (l.stream) (void)hipStreamDestroy(l.stream);
+        if (l.done) (void)hipEventDestroy(l.done);
+        for (hipEvent_t ev : l.stepEv) if (ev) (void)hipEventDestroy(ev);
+        if (l.hostCounters) (void)hipHostFree(l.hostCounters);
+        if (l.mem) (void)hipFree(l.mem);
+    }
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->work) (void)hipFree(c->work);
+    delete c;
+}
+
+namespace {
+
+// Pixels the call covers, in its pixel order, and the Batch fields that describe that order.
+uint64_t call_pixels(const rtgpu_render_settings& st, const TileOrder* order, Batch& proto)
+{
+    const uint32_t tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
+    proto = Batch{};
+    if (!order || order->tileSize == 0) return (uint64_t)tw * th;
+    const uint32_t T = order->tileSize;
+    proto.tileSize = T;
+    proto.nRanks = order->nRanks;
+    proto.rank = order->rank;
+    proto.tilesX = (tw + T - 1) / T;
+    proto.nTiles = proto.tilesX * ((th + T - 1) / T);
+    const uint32_t mine = proto.nTiles > order->rank ? (proto.nTiles - order->rank + order->nRanks - 1) / order->nRanks : 0u;
+    return (uint64_t)mine * T * T;
+}
+
+hipError_t ensure_lane(RenderCache::Lane& l, const PoolDims& dims, std::string& err)
+{
+    hipError_t e = hipSuccess;
+#define EL_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return e; } } while (0)
+    if (!l.stream) EL_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+    if (!l.done) EL_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
+    for (hipEvent_t& ev : l.stepEv) if (!ev) EL_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    if (!l.hostCounters) EL_TRY(hipHostMalloc((void**)&l.hostCounters, (size_t)kMaxSteps * kPoolCounters * sizeof(uint32_t)));
+    if (!(l.dims == dims) || !l.mem) {
+        Pool probe{};
+        const size_t need = pool_carve(probe, nullptr, dims);
+        if (need > l.bytes) {
+            if (l.mem) { EL_TRY(hipStreamSynchronize(l.stream)); (void)hipFree(l.mem); l.mem = nullptr; l.bytes = 0; }
+            e = hipMalloc(&l.mem, need);
+            if (e != hipSuccess) { err = std::string("render workspace: ") + hipGetErrorString(e); return e; }
+            l.bytes = need;
+        }
+        pool_carve(l.pool, (char*)l.mem, dims);
+        l.dims = dims;
+    }
+#undef EL_TRY
+    return hipSuccess;
+}
+
+} // namespace
+
+hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, const TileOrder* order,
+                            float* dOut, rtgpu_render_stats* stats, uint64_t* work, hipStream_t stream, std::string& err, rtgpu_render_profile* profile)
 {
     const SceneView& sv = scene.view;
-    const uint32_t tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
-    const uint64_t nPixelsTotal = (uint64_t)tw * th;
+    Batch proto;
+    const uint64_t nPixelsTotal = call_pixels(st, order, proto);
     if (stats) *stats = rtgpu_render_stats{};
+    if (work) std::memset(work, 0, 9 * sizeof(uint64_t));
     if (nPixelsTotal == 0) return hipSuccess;
+    if (nPixelsTotal >= (1ull << 32)) { err = "more than 2^32 pixels in one call"; return hipErrorInvalidValue; }
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint64_t pathsPerPixel = (uint64_t)G * M;
 
@@ -947,130 +1318,57 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     const uint64_t S = pixelsPerBatch * G;
     if (P >= (1ull << 31)) { err = "geometry_aa * material_aa too large for one batch"; return hipErrorInvalidValue; }
 
-    // Batches are independent (disjoint pixels), so `lanes` of them are in flight at once, each on
-    // its own stream with its own workspace and host thread: the host round trip that reads the
-    // queue sizes after every shade pass and the thin late-bounce launches of one batch overlap
-    // with the other batch's kernels.
+    // Batches are independent (disjoint pixels), so `lanes` of them are in flight at once, each on its own stream
+    // with its own workspace and host thread: the thin late-bounce launches of one batch overlap with the other
+    // batch's kernels.
     const uint64_t nBatches = (nPixelsTotal + pixelsPerBatch - 1) / pixelsPerBatch;
     int lanes = 2;
     if (const char* e = std::getenv("RTGPU_RENDER_LANES")) lanes = std::max(1, std::min(8, std::atoi(e)));
     lanes = (int)std::min<uint64_t>((uint64_t)lanes, nBatches);
+    if (profile) lanes = 1;   // one batch at a time: the launches of two streams would overlap and stretch each other's spans
+    StageTimer timer;
 
-    struct Lane {
-        hipStream_t stream = nullptr;
-        hipEvent_t done = nullptr;
-        uint32_t* hostCounters = nullptr;   // pinned
-        hipError_t e = hipSuccess;
-        std::string err;
-        uint64_t primary = 0, extension = 0, shadow = 0;
-    };
-    std::vector<Lane> L((size_t)lanes);
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (!scene.renderCache) scene.renderCache = new RenderCache();
+    RenderCache& rc = *scene.renderCache;
     hipError_t e = hipSuccess;
-    auto cleanup = [&]() {
-        for (Lane& l : L) {
-            if (l.stream) (void)hipStreamDestroy(l.stream);
-            if (l.done) (void)hipEventDestroy(l.done);
-            if (l.hostCounters) (void)hipHostFree(l.hostCounters);
-        }
-        if (ev0) (void)hipEventDestroy(ev0);
-        if (ev1) (void)hipEventDestroy(ev1);
-    };
-#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); cleanup(); return e; } } while (0)
-    RT_TRY(hipEventCreate(&ev0));
-    RT_TRY(hipEventCreate(&ev1));
-    for (Lane& l : L) {
-        RT_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
-        RT_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
-        RT_TRY(hipHostMalloc((void**)&l.hostCounters, 4 * sizeof(uint32_t)));
+#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); return e; } } while (0)
+    if (!rc.ev0) RT_TRY(hipEventCreate(&rc.ev0));
+    if (!rc.ev1) RT_TRY(hipEventCreate(&rc.ev1));
+    if ((int)rc.lanes.size() < lanes) rc.lanes.resize((size_t)lanes);
+    const PoolDims dims = pool_dims(sv, P, S);
+    for (int li = 0; li < lanes; ++li)
+        if ((e = ensure_lane(rc.lanes[(size_t)li], dims, err)) != hipSuccess) return e;
+    if (work) {
+        if (!rc.work) RT_TRY(hipMalloc((void**)&rc.work, 9 * sizeof(unsigned long long)));
+        RT_TRY(hipMemsetAsync(rc.work, 0, 9 * sizeof(unsigned long long), stream));
     }
-    RT_TRY(hipEventRecord(ev0, stream));
-    for (Lane& l : L) RT_TRY(hipStreamWaitEvent(l.stream, ev0, 0));
-#undef RT_TRY
+    RT_TRY(hipEventRecord(rc.ev0, stream));
+    for (int li = 0; li < lanes; ++li) RT_TRY(hipStreamWaitEvent(rc.lanes[(size_t)li].stream, rc.ev0, 0));
 
+    std::vector<LaneRun> runs((size_t)lanes);
+    std::vector<hipError_t> laneErr((size_t)lanes, hipSuccess);
+    std::vector<std::string> laneMsg((size_t)lanes);
     auto run_lane = [&](int li) {
-        Lane& ln = L[(size_t)li];
+        RenderCache::Lane& cl = rc.lanes[(size_t)li];
+        LaneRun& ln = runs[(size_t)li];
         hipError_t le = hipSetDevice(scene.device);
-#define LN_TRY(call) do { le = (call); if (le != hipSuccess) { ln.e = le; ln.err = std::string(#call) + ": " + hipGetErrorString(le); return; } } while (0)
-        if (le != hipSuccess) { ln.e = le; ln.err = "hipSetDevice failed"; return; }
-        Workspace ws;
-        Pool pool{};
-        pool.rayA = ws.alloc<float4>(P); pool.rayB = ws.alloc<float4>(P); pool.hit = ws.alloc<float4>(P);
-        pool.hitInst = ws.alloc<uint32_t>(sv.singleMesh ? 1 : P);
-        pool.thr = ws.alloc<float4>(P); pool.aux = ws.alloc<float4>(P); pool.result = ws.alloc<float4>(P);
-        pool.glassN = ws.alloc<float4>(sv.hasGlass ? P : 1); pool.glassA = ws.alloc<float4>(sv.hasGlass ? P : 1); pool.glassB = ws.alloc<float4>(sv.hasGlass ? P : 1);
-        pool.acc = ws.alloc<float4>(sv.hasAdd ? P : 1); pool.accPend = ws.alloc<float4>(sv.hasAdd ? P : 1);
-        pool.sA = ws.alloc<float4>(S); pool.sB = ws.alloc<float4>(S); pool.sC = ws.alloc<float4>(S);
-        pool.sLive = ws.alloc<uint8_t>(S); pool.sHasVar = ws.alloc<uint8_t>(S);
-        pool.qA = ws.alloc<uint32_t>(P); pool.qB = ws.alloc<uint32_t>(P); pool.qShadow = ws.alloc<uint32_t>(P);
-        pool.qPhoton = ws.alloc<uint32_t>(sv.pmMode != RTGPU_PM_NONE ? P : 1);
-        pool.qPhotonTail = ws.alloc<uint32_t>(sv.pmMode != RTGPU_PM_NONE ? P : 1);
-        const size_t nC = sv.pmMode == RTGPU_PM_CAUSTICS ? P : 1;
-        pool.cHit = ws.alloc<float4>(nC); pool.cDir = ws.alloc<float4>(nC); pool.cThrColor = ws.alloc<float4>(nC); pool.cBase = ws.alloc<float4>(nC);
-        pool.counters = ws.alloc<uint32_t>(kPoolCounters);
-        if (ws.err != hipSuccess) { ln.e = ws.err; ln.err = std::string("render workspace: ") + hipGetErrorString(ws.err); return; }
-        const hipStream_t ls = ln.stream;
-        uint32_t* h = ln.hostCounters;
-        const int mode = trace_mode(sv);
-        const bool gatherStats = std::getenv("RTGPU_GATHER_STATS") != nullptr;
-        const uint32_t tailCap = std::getenv("RTGPU_GATHER_TAIL_BLOCKS") ? (uint32_t)std::atoi(std::getenv("RTGPU_GATHER_TAIL_BLOCKS")) : 16384u;
-        const bool rich = sv.hasGlass || sv.hasAdd || sv.hasNormalMap || sv.pmMode != RTGPU_PM_NONE;
+        if (le != hipSuccess) { laneErr[(size_t)li] = le; laneMsg[(size_t)li] = "hipSetDevice failed"; return; }
+        ln.stream = cl.stream;
+        ln.pool = cl.pool;
+        ln.hostCounters = cl.hostCounters;
+        for (int k = 0; k < 4; ++k) ln.stepEv[k] = cl.stepEv[k];
+        ln.work = work ? rc.work : nullptr;
+        ln.timer = profile ? &timer : nullptr;
         for (uint64_t bi = (uint64_t)li; bi < nBatches; bi += (uint64_t)lanes) {
             const uint64_t start = bi * pixelsPerBatch;
-            Batch batch;
+            Batch batch = proto;
             batch.pixelStart = (uint32_t)start;
             batch.nPixels = (uint32_t)std::min<uint64_t>(pixelsPerBatch, nPixelsTotal - start);
-            const uint32_t nS = batch.nPixels * G;
-            const uint32_t nP = nS * M;
-            LN_TRY(hipMemsetAsync(pool.counters, 0, kPoolCounters * sizeof(uint32_t), ls));
-            if (mode == kTraceSingle) hipLaunchKernelGGL((primary_kernel<kTraceSingle>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
-            else if (mode == kTraceInstances) hipLaunchKernelGGL((primary_kernel<kTraceInstances>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
-            else hipLaunchKernelGGL((primary_kernel<kTraceLanes>), dim3((nS + 63) / 64), dim3(64), 0, ls, sv, pool, cam, st, batch);
-            ln.primary += nS;
-            uint32_t nActive = nP;   // the first shade pass runs over every path of the batch
-            uint32_t* qIn = pool.qA;
-            uint32_t* qOut = pool.qB;
-            // at most one glossy re-trace step per vertex on top of the vertex steps
-            for (int step = 0; nActive > 0 && step < 2 * st.max_path_length + 2; ++step) {
-                if (step > 0) LN_TRY(hipMemsetAsync(pool.counters, 0, kPoolCounters * sizeof(uint32_t), ls));
-                const dim3 shadeGrid((nActive + kShadeBlock - 1) / kShadeBlock), shadeBlock(kShadeBlock);
-                if (rich) {
-                    if (step == 0) hipLaunchKernelGGL((shade_kernel<true, true>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
-                    else hipLaunchKernelGGL((shade_kernel<false, true>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
-                } else {
-                    if (step == 0) hipLaunchKernelGGL((shade_kernel<true, false>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
-                    else hipLaunchKernelGGL((shade_kernel<false, false>), shadeGrid, shadeBlock, 0, ls, sv, pool, st, batch, qIn, nActive, qOut);
-                }
-                LN_TRY(hipMemcpyAsync(h, pool.counters, 4 * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
-                LN_TRY(hipStreamSynchronize(ls));
-                const uint32_t nExt = h[0], nShadow = h[1], nPhoton = h[2], nRepeated = h[3];
-                if (nPhoton) {
-                    hipLaunchKernelGGL(photon_gather_stage_kernel, dim3((nPhoton + 63) / 64), dim3(64), 0, ls, sv, pool, nPhoton);
-                    hipLaunchKernelGGL(photon_gather_tail_kernel, dim3(std::min(nPhoton, tailCap)), dim3(64), 0, ls, sv, pool);
-                    if (gatherStats) {
-                        uint32_t t = 0;
-                        LN_TRY(hipMemcpyAsync(&t, pool.counters + 4, 4, hipMemcpyDeviceToHost, ls));
-                        LN_TRY(hipStreamSynchronize(ls));
-                        std::fprintf(stderr, "gather: %u queued, %u in the tail\n", nPhoton, t);
-                    }
-                }
-                if (nShadow || nExt) {
-                    const uint32_t blocks = (nExt + 63) / 64 + (nShadow + 63) / 64;
-                    if (mode == kTraceSingle) hipLaunchKernelGGL((trace_stage_kernel<kTraceSingle>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
-                    else if (mode == kTraceInstances) hipLaunchKernelGGL((trace_stage_kernel<kTraceInstances>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
-                    else hipLaunchKernelGGL((trace_stage_kernel<kTraceLanes>), dim3(blocks), dim3(64), 0, ls, sv, pool, qOut, nExt, nShadow);
-                }
-                ln.extension += nExt - nRepeated;
-                ln.shadow += nShadow;
-                std::swap(qIn, qOut);
-                nActive = nExt;
-            }
-            hipLaunchKernelGGL(resolve_kernel, dim3((batch.nPixels + 255) / 256), dim3(256), 0, ls, pool, st, batch, dRgb);
-            LN_TRY(hipGetLastError());
+            le = run_batch(sv, ln, cam, st, batch, dOut, laneMsg[(size_t)li]);
+            if (le != hipSuccess) { laneErr[(size_t)li] = le; return; }
         }
-        LN_TRY(hipEventRecord(ln.done, ls));
-        LN_TRY(hipStreamSynchronize(ls));   // the workspace is freed when this function returns
-#undef LN_TRY
+        le = hipEventRecord(cl.done, cl.stream);
+        if (le != hipSuccess) { laneErr[(size_t)li] = le; laneMsg[(size_t)li] = "hipEventRecord failed"; }
     };
     {
         std::vector<std::thread> threads;
@@ -1078,20 +1376,53 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
         run_lane(0);
         for (std::thread& t : threads) t.join();
     }
-    for (Lane& l : L)
-        if (l.e != hipSuccess) { e = l.e; err = l.err; cleanup(); return e; }
-#define RT_TRY(call) do { e = (call); if (e != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e); cleanup(); return e; } } while (0)
-    for (Lane& l : L) RT_TRY(hipStreamWaitEvent(stream, l.done, 0));
-    RT_TRY(hipEventRecord(ev1, stream));
+    for (int li = 0; li < lanes; ++li)
+        if (laneErr[(size_t)li] != hipSuccess) {
+            // leave nothing in flight on the cached streams before reporting
+            for (int k = 0; k < lanes; ++k) (void)hipStreamSynchronize(rc.lanes[(size_t)k].stream);
+            err = laneMsg[(size_t)li];
+            return laneErr[(size_t)li];
+        }
+    for (int li = 0; li < lanes; ++li) RT_TRY(hipStreamWaitEvent(stream, rc.lanes[(size_t)li].done, 0));
+    RT_TRY(hipEventRecord(rc.ev1, stream));
     RT_TRY(hipStreamSynchronize(stream));
     if (stats) {
         float ms = 0;
-        RT_TRY(hipEventElapsedTime(&ms, ev0, ev1));
-        for (Lane& l : L) { stats->primary_rays += l.primary; stats->extension_rays += l.extension; stats->shadow_rays += l.shadow; }
+        RT_TRY(hipEventElapsedTime(&ms, rc.ev0, rc.ev1));
+        for (const LaneRun& l : runs) { stats->extension_rays += l.extension; stats->shadow_rays += l.shadow; }
+        // one primary ray per geometry sample of every pixel of the call (the padding of squares that stick out is not traced)
+        uint64_t pixels = nPixelsTotal;
+        if (proto.tileSize) {
+            pixels = 0;
+            const uint32_t T = proto.tileSize, tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
+            for (uint32_t k = proto.rank; k < proto.nTiles; k += proto.nRanks) {
+                const uint32_t x0 = (k % proto.tilesX) * T, y0 = (k / proto.tilesX) * T;
+                pixels += (uint64_t)std::min(T, tw - x0) * std::min(T, th - y0);
+            }
+        }
+        stats->primary_rays = pixels * G;
         stats->device_ms = ms;
     }
+    if (profile) {
+        *profile = rtgpu_render_profile{};
+        double* ms[kStageCount] = {&profile->primary_ms, &profile->shade_ms, &profile->trace_ms, &profile->gather_ms, &profile->resolve_ms};
+        uint32_t* n[kStageCount] = {&profile->primary_launches, &profile->shade_launches, &profile->trace_launches, &profile->gather_launches, &profile->resolve_launches};
+        for (const StageTimer::Span& sp : timer.spans) {
+            float t = 0;
+            RT_TRY(hipEventElapsedTime(&t, timer.events[sp.a], timer.events[sp.b]));
+            *ms[sp.stage] += t;
+            *n[sp.stage] += 1;
+        }
+        float total = 0;
+        RT_TRY(hipEventElapsedTime(&total, rc.ev0, rc.ev1));
+        profile->total_ms = total;
+    }
+    if (work) {
+        unsigned long long h[9];
+        RT_TRY(hipMemcpy(h, rc.work, sizeof(h), hipMemcpyDeviceToHost));
+        for (int k = 0; k < 9; ++k) work[k] = h[k];
+    }
 #undef RT_TRY
-    cleanup();
     return hipSuccess;
 }
 

@@ -387,9 +387,14 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
 {
     SceneView& v = scene.view;
     PH_HIP(hipSetDevice(scene.device));
+    // copies of the scene on other devices (multi-GPU renders) hold the old map: they are made again when next needed
+    destroy_multi(scene.multi);
+    scene.multi = nullptr;
     for (const void* p : {(const void*)v.kdPos, (const void*)v.kdNormal, (const void*)v.kdEnergy})
         if (p) (void)hipFree(const_cast<void*>(p));
-    v.kdPos = v.kdNormal = v.kdEnergy = nullptr;
+    scene.set_array(&SceneView::kdPos, (const float4*)nullptr, 0);
+    scene.set_array(&SceneView::kdNormal, (const float4*)nullptr, 0);
+    scene.set_array(&SceneView::kdEnergy, (const float4*)nullptr, 0);
     v.nPhotons = 0;
     v.pmMode = RTGPU_PM_NONE;
     v.pmDepth = 0;
@@ -423,11 +428,11 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
         clock.lap("normal cones");
         void *dp = nullptr, *dn = nullptr, *de = nullptr;
         PH_HIP(hipMalloc(&dp, 2 * n * sizeof(float4)));
-        v.kdPos = (const float4*)dp;
+        scene.set_array(&SceneView::kdPos, (const float4*)dp, 2 * n * sizeof(float4));
         PH_HIP(hipMalloc(&dn, n * sizeof(float4)));
-        v.kdNormal = (const float4*)dn;
+        scene.set_array(&SceneView::kdNormal, (const float4*)dn, n * sizeof(float4));
         PH_HIP(hipMalloc(&de, n * sizeof(float4)));
-        v.kdEnergy = (const float4*)de;
+        scene.set_array(&SceneView::kdEnergy, (const float4*)de, n * sizeof(float4));
         PH_HIP(hipMemcpy(dp, pos, 2 * n * sizeof(float4), hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(dn, nrm, n * sizeof(float4), hipMemcpyHostToDevice));
         PH_HIP(hipMemcpy(de, en, n * sizeof(float4), hipMemcpyHostToDevice));

@@ -1,19 +1,81 @@
-"""Image-space sharding of a render over the ranks of one node and the frame-buffer gather.
+"""One frame over the ranks of a node: the square order of the library's multi-GPU path and the frame gather.
 
 The reference scales out with separate processes that render disjoint tiles
 (--xstart/--xend/--ystart/--yend, exe/Raytracer.cpp:65-68), write TILE files (io/TileFile.cpp:8-27)
 and paste them together with --mergetiles (exe/Raytracer.cpp:260-277, io/TileFile.cpp:29-70).  Here
-one process per GPU renders an interleaved set of row bands of the frame (scene replicated on every
-GPU) and the bands are gathered to rank 0 with one collective (RCCL over xGMI when the process
-group is "nccl"; "gloo" on CPU tensors in the tests).  Pixels are keyed by their global pixel
-index in the RNG, so the assembled image is bit-identical for every world size.
+the settings' tile is cut into T x T squares numbered row by row, square k belongs to rank k % world,
+every rank (one process per GPU, scene replicated) renders its squares into a compact buffer
+(rtgpu_render_tiles_device) and the buffers meet on rank 0:
+
+* natively, through the library's RCCL send / receive pairs over xGMI and its scatter kernel
+  (api.Comm.gather_tiles_device) -- the measured path;
+* through a torch.distributed gather of equal padded buffers ("gloo" on host copies: the CPU
+  rehearsals of the tests, and the stand-in when the native communicator cannot be made).
+
+Pixels are keyed by their frame position in the RNG, so the assembled frame is bit-identical for
+every world size.  The functions on numpy arrays below are the host-side model of the square order
+(what rt_multi.hip computes on the device); the tests hold one against the other.
 """
 from __future__ import annotations
 
-from typing import Callable, List, Tuple
+from typing import List, Tuple
 
 import numpy as np
 
+TILE_SIZE = 32
+
+
+# ---- the square order (host model) -------------------------------------------------------------
+
+def tile_grid(settings, tile_size: int = TILE_SIZE) -> Tuple[int, int]:
+    """(squares per row, squares in all) over the settings' tile."""
+    tw, th = settings.x_end - settings.x_start, settings.y_end - settings.y_start
+    tiles_x = -(-tw // tile_size)
+    return tiles_x, tiles_x * -(-th // tile_size)
+
+
+def rank_tile_count(n_tiles: int, rank: int, world: int) -> int:
+    return (n_tiles - rank + world - 1) // world if n_tiles > rank else 0
+
+
+def tile_buffer_floats(settings, tile_size: int, rank: int, world: int) -> int:
+    """Floats of a rank's compact buffer (mirror of rtgpu_tile_buffer_floats)."""
+    _, n_tiles = tile_grid(settings, tile_size)
+    return rank_tile_count(n_tiles, rank, world) * tile_size * tile_size * 3
+
+
+def compact_from_frame(frame: np.ndarray, settings, tile_size: int, rank: int, world: int) -> np.ndarray:
+    """The compact buffer rank `rank` would hold if it rendered `frame` ((H, W, 3)): its squares one after the
+    other, each row by row, pixels outside the tile zero."""
+    T = tile_size
+    tiles_x, n_tiles = tile_grid(settings, T)
+    out = np.zeros((rank_tile_count(n_tiles, rank, world), T, T, 3), dtype=np.float32)
+    for j in range(out.shape[0]):
+        k = j * world + rank
+        x0, y0 = settings.x_start + (k % tiles_x) * T, settings.y_start + (k // tiles_x) * T
+        x1, y1 = min(x0 + T, settings.x_end), min(y0 + T, settings.y_end)
+        out[j, :y1 - y0, :x1 - x0] = frame[y0:y1, x0:x1]
+    return out.reshape(-1)
+
+
+def scatter_to_frame(buffers: List[np.ndarray], settings, tile_size: int, frame: np.ndarray = None) -> np.ndarray:
+    """Rank 0's last step: the ranks' compact buffers written into FrameBuffer order (pixels outside the
+    settings' tile keep what `frame` held)."""
+    T, world = tile_size, len(buffers)
+    tiles_x, n_tiles = tile_grid(settings, T)
+    if frame is None:
+        frame = np.zeros((settings.height, settings.width, 3), dtype=np.float32)
+    for rank, buf in enumerate(buffers):
+        sq = np.asarray(buf, dtype=np.float32).reshape(-1, T, T, 3)
+        for j in range(rank_tile_count(n_tiles, rank, world)):
+            k = j * world + rank
+            x0, y0 = settings.x_start + (k % tiles_x) * T, settings.y_start + (k // tiles_x) * T
+            x1, y1 = min(x0 + T, settings.x_end), min(y0 + T, settings.y_end)
+            frame[y0:y1, x0:x1] = sq[j, :y1 - y0, :x1 - x0]
+    return frame
+
+
+# ---- row bands: the rectangles separate reference processes would render into TILE files ---------
 
 def band_height(height: int, world: int, bands_per_rank: int = 4) -> int:
     """Rows per band: about bands_per_rank interleaved bands for every rank, at least 1 row."""
@@ -21,8 +83,7 @@ def band_height(height: int, world: int, bands_per_rank: int = 4) -> int:
 
 
 def rank_bands(height: int, world: int, rank: int, bands_per_rank: int = 4) -> List[Tuple[int, int]]:
-    """Half-open row ranges [y0, y1) of `rank`: band b goes to rank b % world (interleaved so that
-    an unevenly expensive image still balances)."""
+    """Half-open row ranges [y0, y1) of `rank`: band b goes to rank b % world."""
     bh = band_height(height, world, bands_per_rank)
     out = []
     b = 0
@@ -33,83 +94,75 @@ def rank_bands(height: int, world: int, rank: int, bands_per_rank: int = 4) -> L
     return out
 
 
-def padded_rows(height: int, world: int, bands_per_rank: int = 4) -> int:
-    """Rows of the equal-sized per-rank message (the largest rank's row count)."""
-    return max(sum(y1 - y0 for y0, y1 in rank_bands(height, world, r, bands_per_rank)) for r in range(world))
+# ---- the gather ------------------------------------------------------------------------------------
 
-
-def render_sharded(render_band: Callable, width: int, height: int, rank: int, world: int, torch_device,
-                   group=None, bands_per_rank: int = 4):
-    """Renders this rank's bands and gathers the frame on rank 0.
-
-    render_band(y0, y1, out) must fill `out` (a (y1-y0, width, 3) float32 torch tensor on
-    torch_device) with the rows [y0, y1) of the image.  Returns the (height, width, 3) float32
-    frame on rank 0 and None elsewhere.
-    """
+def gather_compact(local, settings, tile_size: int, rank: int, world: int, group=None):
+    """torch.distributed gather of the ranks' compact buffers (padded to rank 0's size, the largest) to rank 0 and the
+    scatter into frame order there.  `local`: 1-D float32 torch tensor (CPU or GPU).  Returns the (H, W, 3) frame on rank 0
+    (a device tensor when the exchange ran on device tensors, else a numpy array), None elsewhere.  The rehearsal / stand-in path: the measured one is api.Comm."""
     import torch
     import torch.distributed as dist
 
-    bands = rank_bands(height, world, rank, bands_per_rank)
-    rows = padded_rows(height, world, bands_per_rank)
-    local = torch.zeros((rows, width, 3), dtype=torch.float32, device=torch_device)
-    r = 0
-    for y0, y1 in bands:
-        render_band(y0, y1, local[r:r + (y1 - y0)])
-        r += y1 - y0
+    stride = tile_buffer_floats(settings, tile_size, 0, world)
+    if world > 1 and local.is_cuda and dist.get_backend(group) != "gloo":
+        # device tensors end to end: the ranks' buffers land side by side and the library's scatter kernel writes the frame
+        from . import api
+        padded = torch.zeros(stride, dtype=torch.float32, device=local.device)
+        padded[:local.numel()] = local
+        big = torch.empty(world * stride, dtype=torch.float32, device=local.device) if rank == 0 else None
+        dist.gather(padded, list(big.view(world, stride).unbind(0)) if rank == 0 else None, dst=0, group=group)
+        if rank != 0:
+            return None
+        frame = torch.zeros((settings.height, settings.width, 3), dtype=torch.float32, device=local.device)
+        api.scatter_tiles_device(settings, tile_size, world, big, frame, torch.cuda.current_stream())
+        return frame
     if world == 1:
-        gathered = [local]
-    elif local.is_cuda and dist.get_backend(group) == "gloo":
-        # a CPU process group (rehearsals without RCCL): stage the exchange through host memory
-        host = local.cpu()
-        parts = [torch.empty_like(host) for _ in range(world)] if rank == 0 else None
-        dist.gather(host, parts, dst=0, group=group)
-        gathered = [t.to(local.device) for t in parts] if rank == 0 else None
+        parts = [local]
     else:
-        gathered = [torch.empty_like(local) for _ in range(world)] if rank == 0 else None
-        dist.gather(local, gathered, dst=0, group=group)
+        padded = torch.zeros(stride, dtype=torch.float32, device=local.device)
+        padded[:local.numel()] = local
+        if padded.is_cuda and dist.get_backend(group) == "gloo":
+            padded = padded.cpu()
+        parts = [torch.empty_like(padded) for _ in range(world)] if rank == 0 else None
+        dist.gather(padded, parts, dst=0, group=group)
     if rank != 0:
         return None
-    frame = torch.empty((height, width, 3), dtype=torch.float32, device=torch_device)
-    for src in range(world):
-        r = 0
-        for y0, y1 in rank_bands(height, world, src, bands_per_rank):
-            frame[y0:y1] = gathered[src][r:r + (y1 - y0)]
-            r += y1 - y0
-    return frame
+    bufs = [p.detach().cpu().numpy()[:tile_buffer_floats(settings, tile_size, r, world)] for r, p in enumerate(parts)]
+    return scatter_to_frame(bufs, settings, tile_size)
 
 
-def render_frame_distributed(scene, cam, settings, rank: int, world: int, torch_device, group=None,
-                             bands_per_rank: int = 4, stream=None):
-    """Sharded Renderer::render of the whole frame through the C ABI (GPU ranks).
+class FrameSharder:
+    """One rank of a frame rendered over `world` GPUs (one process each) through the C ABI.
 
-    Returns (frame on rank 0 or None, ray statistics of this rank as a dict)."""
-    import torch
+    comm: an api.Comm (the library's RCCL gather), or None to gather with torch.distributed (`group`).
+    Buffers are kept between frames."""
 
-    from . import abi, api
+    def __init__(self, scene, rank: int, world: int, torch_device, comm=None, group=None, tile_size: int = TILE_SIZE):
+        self.scene, self.rank, self.world, self.device = scene, rank, world, torch_device
+        self.comm, self.group, self.tile_size = comm, group, tile_size
+        self._tiles = None
+        self._frame = None
 
-    W, H = settings.width, settings.height
-    full = torch.zeros((H, W, 3), dtype=torch.float32, device=torch_device)
-    totals = {"primary_rays": 0, "extension_rays": 0, "shadow_rays": 0, "device_ms": 0.0}
-    renderer = api.Renderer()
+    def render(self, cam, settings, stream=None):
+        """Returns (frame, ray statistics of this rank).  frame: on rank 0 the (H, W, 3) float32 device tensor (native
+        gather) or numpy array (torch gather); None elsewhere.  The gather is enqueued on `stream` (the current torch
+        stream when None); the caller synchronises."""
+        import torch
 
-    def render_band(y0, y1, out):
-        st = abi.RenderSettings.from_buffer_copy(settings)
-        st.x_start, st.x_end, st.y_start, st.y_end = 0, W, y0, y1
-        stats = renderer.render_device(scene, cam, st, full, stream)
-        out.copy_(full[y0:y1])
-        totals["primary_rays"] += int(stats.primary_rays)
-        totals["extension_rays"] += int(stats.extension_rays)
-        totals["shadow_rays"] += int(stats.shadow_rays)
-        totals["device_ms"] += float(stats.device_ms)
+        from . import api
 
-    frame = render_sharded(render_band, W, H, rank, world, torch_device, group, bands_per_rank)
-    return frame, totals
-
-
-def assemble_reference(height: int, width: int, world: int, fill: Callable[[int, int], np.ndarray], bands_per_rank: int = 4):
-    """Host-side model of the gather: what rank 0 must end up with (used by the tests)."""
-    frame = np.empty((height, width, 3), dtype=np.float32)
-    for rnk in range(world):
-        for y0, y1 in rank_bands(height, world, rnk, bands_per_rank):
-            frame[y0:y1] = fill(y0, y1)
-    return frame
+        stream = stream if stream is not None else torch.cuda.current_stream()
+        n = api.tile_buffer_floats(settings, self.tile_size, self.rank, self.world)
+        if self._tiles is None or self._tiles.numel() < max(n, 1):
+            self._tiles = torch.empty(max(n, 1), dtype=torch.float32, device=self.device)
+        stats = api.Renderer().render_tiles_device(self.scene, cam, settings, self.tile_size, self.rank, self.world, self._tiles, stream)
+        if self.comm is None:
+            return gather_compact(self._tiles[:n], settings, self.tile_size, self.rank, self.world, self.group), stats
+        frame = None
+        if self.rank == 0:
+            shape = (settings.height, settings.width, 3)
+            if self._frame is None or tuple(self._frame.shape) != shape:
+                self._frame = torch.zeros(shape, dtype=torch.float32, device=self.device)
+            frame = self._frame
+        self.comm.gather_tiles_device(settings, self.tile_size, self._tiles, frame, stream)
+        return frame, stats

@@ -257,6 +257,46 @@ def blob_scene(subdiv=8, seed=7):
     return sc, cam_m, yfov
 
 
+def blob_room_scene(subdiv=8, seed=7, wall_grid=24):
+    """The ~1 M-triangle scene of the path-traced throughput figure: the config-2 blob (20 * 4^subdiv triangles, about
+    70 % of its surface diffuse grey and 30 % glossy in bands, like the material mix of config 3) standing in a closed
+    room (six tessellated walls, a glossy floor) lit by an area light under the ceiling and a point light, seen from
+    the camera of config 2.  One mesh, per-triangle materials.  Paths bounce between the blob and the walls, so
+    extension and shadow rays are incoherent and most of them have to search the blob's tree."""
+    blob = displaced_icosphere(subdiv, seed)
+    v, f = blob.vertices.astype(np.float64), blob.indices
+    cy = v[f].mean(axis=1)[:, 1]
+    glossy = np.sin(7.0 * cy + 0.4) > 0.45
+    ymin = float(v[:, 1].min())
+    R = 6.0
+    y0, y1 = ymin - 0.05, ymin - 0.05 + 2 * R
+    g = wall_grid
+    parts = [(v, f[~glossy], 0), (v, f[glossy], 1),
+             (*grid_quad((-R, y0, -R), (0, 0, 2 * R), (2 * R, 0, 0), g, g), 1),        # floor (glossy), normal +y
+             (*grid_quad((-R, y1, -R), (2 * R, 0, 0), (0, 0, 2 * R), g, g), 0),        # ceiling, normal -y
+             (*grid_quad((-R, y0, -R), (2 * R, 0, 0), (0, 2 * R, 0), g, g), 2),        # z = -R wall, normal +z
+             (*grid_quad((-R, y0, R), (0, 2 * R, 0), (2 * R, 0, 0), g, g), 3),         # z = +R wall, normal -z
+             (*grid_quad((-R, y0, -R), (0, 2 * R, 0), (0, 0, 2 * R), g, g), 0),        # x = -R wall, normal +x
+             (*grid_quad((R, y0, -R), (0, 0, 2 * R), (0, 2 * R, 0), g, g), 0)]         # x = +R wall, normal -x
+    mesh = _merge(parts)
+    # the blob's two parts share one vertex array: its smooth normals must come from all of its faces
+    nb = len(v)
+    mesh.normals[:nb] = blob.normals
+    mesh.normals[nb:2 * nb] = blob.normals
+    sc = SceneData()
+    sc.meshes = [mesh]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.7, 0.7, 0.7)), MaterialData(MAT_GLOSSY, (0.9, 0.9, 0.9), roughness=0.2),
+                    MaterialData(MAT_DIFFUSE, (0.7, 0.25, 0.2)), MaterialData(MAT_DIFFUSE, (0.2, 0.3, 0.7))]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    sc.area_lights = [((-1.5, y1 - 0.05, -1.0), (1.5, y1 - 0.05, -1.0), (0.0, y1 - 0.05, 1.6), (1.0, 0.95, 0.85), 700.0)]
+    sc.point_lights = [((3.0, 4.0, 5.0), (0.9, 0.95, 1.0), 400.0)]
+    yfov = 0.6
+    radius = float(np.linalg.norm(blob.vertices, axis=1).mean())
+    dist = radius / (0.95 * math.tan(yfov / 2.0))
+    cam_m = look_at((0.35 * dist, 0.25 * dist, dist * 0.9), (0.0, 0.0, 0.0))
+    return sc, cam_m, yfov
+
+
 def cluster_scene(copies=38, subdiv=8, flatten=True, seed=7):
     """Config 5: `copies` translated copies of the config-2 mesh on a jittered lattice (38 copies of
     1 310 720 triangles = 49.8 M), either flattened into one triangle soup (what --soupify makes of

@@ -1,5 +1,5 @@
-"""bench.py end to end: the one-line JSON contract at N = 1, and the multi-rank flow (barriers, max over
-ranks, sharded frame + gather) rehearsed with two ranks sharing this box's GPU over gloo -- the measured
+"""bench.py end to end: the one-line JSON contract at N = 1 (reduced frame size), and the multi-rank flow (barriers,
+max over ranks, squares per rank + gather) rehearsed with two ranks sharing this box's GPU over gloo -- the measured
 multi-GPU configuration is one rank per GPU over RCCL, which needs a multi-GPU node."""
 import json
 import os
@@ -11,7 +11,8 @@ import pytest
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
-        "dtype", "data", "config", "roofline"}
+        "dtype", "data", "config"}
+SMALL = ["--width", "960", "--height", "540", "--gaa", "4", "--maa", "4", "--subdiv", "6"]
 
 
 def check_line(out, n_gpus, steps):
@@ -19,26 +20,37 @@ def check_line(out, n_gpus, steps):
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert KEYS <= set(d) and d["n_gpus"] == n_gpus and d["steps"] == steps and d["unit"] == "Mrays/s"
-    assert d["value"] > 100 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
-    r = d["roofline"]
-    assert r["bound"] == "hbm" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert "workload" in d["config"] and "model" not in d["config"]
-    assert d["frame"]["ms_per_frame"] > 0 and d["frame"]["rays_per_frame"] > 1e8
+    assert d["value"] > 100 and d["higher_is_better"] is True and d["scaling"] == "strong" and d["vs_baseline"] is None
+    assert "workload" in d["config"] and "model" not in d["config"] and "%d GPU(s)" % n_gpus in d["config"]["workload"]
+    assert d["config"]["rays_per_frame"] > 1e7 and d["config"]["non_finite_pixels"] < 10
     return d
 
 
+def check_roofline(r):
+    assert r["bound"] in ("l2", "hbm") and r["peak"] in (34500.0, 8000.0) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert 0 < r["frac"] < 1
+
+
 def test_bench_single_gpu_line():
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "5", "--warmup", "1", "--no-cpu-baseline"],
-                       capture_output=True, text=True, timeout=300, cwd=ROOT)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--no-c5"] + SMALL,
+                       capture_output=True, text=True, timeout=400, cwd=ROOT)
     assert p.returncode == 0, p.stderr[-2000:]
-    check_line(p.stdout, 1, 5)
+    d = check_line(p.stdout, 1, 2)
+    check_roofline(d["roofline"])
+    assert d["roofline"]["kernel"].startswith("trace_stage_kernel") and d["roofline"]["extension"]["rays"] > 0
+    assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_tile_vs_oracle_rel_rmse"] < 1e-3
+    ex = d["extras"]
+    check_roofline(ex["configs[1]"]["primary"]["roofline"])
+    check_roofline(ex["configs[1]"]["bounce"]["roofline"])
+    check_roofline(ex["configs[2]"]["roofline"])
+    assert ex["configs[2]"]["ms_per_frame"] > 0 and ex["configs[2]"]["rays_per_frame"] > 1e8
 
 
 def test_bench_two_ranks_rehearsal_over_gloo():
     env = dict(os.environ, RTGPU_BENCH_BACKEND="gloo")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1"],
+                        "--master-port", "29517", os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"] + SMALL,
                        capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
-    d = check_line(p.stdout, 2, 4)
-    assert "cpu_baseline" not in d and "2 GPU(s)" in d["frame"]["workload"]
+    d = check_line(p.stdout, 2, 2)
+    assert "cpu_baseline" not in d and "extras" not in d and "rehearsal" in d["config"]["gather"]

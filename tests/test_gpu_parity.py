@@ -374,26 +374,108 @@ def test_render_tile_and_batching_do_not_change_pixels():
 
 
 def test_sharded_frame_is_bit_identical_to_single_pass():
-    """The multi-GPU decomposition (interleaved row bands) on one GPU: assembling the bands of
-    world = 1, 2, 4 gives the same frame bit for bit."""
+    """The multi-GPU decomposition on one GPU: the squares of rank 0..G-1 rendered one after the other into compact
+    buffers (rtgpu_render_tiles_device) and written back by the gather's last step (rtgpu_scatter_tiles_device) give the
+    single-pass frame bit for bit, for G = 1, 2, 4, 8; the buffers are what the host-side model of the square order
+    says; a sub-tile leaves the rest of the frame alone."""
     import torch
     from raytracer_amd import distributed
     sc, cam_m, yfov = scenes.box_scene()
-    W, H = 32, 26
+    W, H, T = 45, 38, 8
     cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
-    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=9)
+    dev = torch.device("cuda", 0)
+    with api.Scene(sc) as g:
+        for tile in (None, (5, 3, 41, 30)):
+            st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=9, tile=tile)
+            full = np.full((H, W, 3), -1.0, np.float32)
+            api.Renderer().render(g, cam, st, full)
+            for world in (1, 2, 4, 8):
+                stride = api.tile_buffer_floats(st, T, 0, world)
+                assert stride == distributed.tile_buffer_floats(st, T, 0, world)
+                d_all = torch.zeros(world * stride, dtype=torch.float32, device=dev)
+                for rank in range(world):
+                    n = api.tile_buffer_floats(st, T, rank, world)
+                    assert n == distributed.tile_buffer_floats(st, T, rank, world)
+                    api.Renderer().render_tiles_device(g, cam, st, T, rank, world, d_all[rank * stride:])
+                    torch.cuda.synchronize()
+                    want = distributed.compact_from_frame(full, st, T, rank, world)
+                    assert np.array_equal(d_all[rank * stride:rank * stride + n].cpu().numpy(), want)
+                d_frame = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+                api.scatter_tiles_device(st, T, world, d_all, d_frame, torch.cuda.current_stream())
+                torch.cuda.synchronize()
+                assert np.array_equal(d_frame.cpu().numpy(), full)
+
+
+def test_single_rank_communicator_and_gather():
+    """The RCCL side on the one GPU a test box has: a communicator of one rank is made from a fresh id, the gather of a
+    world of one is the scatter of rank 0's own buffer, and the frame equals the single-pass render."""
+    import torch
+    from raytracer_amd import distributed
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 40, 30
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=2, seed=3)
     dev = torch.device("cuda", 0)
     with api.Scene(sc) as g:
         full, _ = api.Renderer().render(g, cam, st)
-        for world in (1, 2, 4):
-            frame = np.zeros_like(full)
-            for rank in range(world):
-                fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
-                for y0, y1 in distributed.rank_bands(H, world, rank):
-                    bst = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=9, tile=(0, y0, W, y1))
-                    api.Renderer().render_device(g, cam, bst, fb)
-                    frame[y0:y1] = fb[y0:y1].cpu().numpy()
-            assert np.array_equal(frame, full)
+        comm = api.Comm(api.comm_unique_id(), 0, 1)
+        sharder = distributed.FrameSharder(g, 0, 1, dev, comm=comm, tile_size=16)
+        for _ in range(2):
+            frame, stats = sharder.render(cam, st)
+            torch.cuda.synchronize()
+            assert np.array_equal(frame.cpu().numpy(), full) and stats.primary_rays == W * H * 2
+        comm.close()
+        # the stand-in gather (torch.distributed, world of one: no process group needed)
+        frame, _ = distributed.FrameSharder(g, 0, 1, dev, comm=None, tile_size=16).render(cam, st)
+        assert np.array_equal(frame, full)
+        # rtgpu_render with n_gpus = 1 is the plain render; asking for more devices than the box has is an error, not a hang
+        st.n_gpus = 1
+        one, _ = api.Renderer().render(g, cam, st)
+        assert np.array_equal(one, full)
+        st.n_gpus = api.device_count() + 1
+        with pytest.raises(api.RtgpuError):
+            api.Renderer().render(g, cam, st)
+
+
+def test_scene_copy_on_the_same_device_renders_identically():
+    """rtgpu_scene_replicate (what rtgpu_render with n_gpus > 1 does for every other device), here onto the scene's own
+    device: the copy answers queries and renders like the original, with a photon map installed as well."""
+    sc, cam_m, yfov = scenes.box_scene(with_mirror=True)
+    W, H = 32, 24
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=4)
+    with api.Scene(sc) as g:
+        g.build_photon_map(abi.PM_FULL, 1, 5000, 5000, seed=2)
+        a, _ = api.Renderer().render(g, cam, st)
+        with g.replicate(0) as h:
+            b, _ = api.Renderer().render(h, cam, st)
+            assert np.array_equal(a, b)
+            assert h.info().n_triangles == g.info().n_triangles and len(h.photons()) == len(g.photons())
+
+
+def test_render_work_counts_and_same_image():
+    """rtgpu_render_work_device: the counting render gives the image of the ordinary one and ray counts that match its
+    statistics; boxes and triangles per ray are in the range the tree allows."""
+    import torch
+    sc, cam_m, yfov = scenes.box_scene()
+    W, H = 48, 36
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=6)
+    dev = torch.device("cuda", 0)
+    with api.Scene(sc) as g:
+        a = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        b = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        stats = api.Renderer().render_device(g, cam, st, a)
+        work = api.Renderer().render_work_device(g, cam, st, b)
+        assert torch.equal(a, b)
+        assert work.primary_rays == stats.primary_rays == W * H * 2
+        assert work.shadow_rays == stats.shadow_rays
+        assert work.extension_rays >= stats.extension_rays       # the statistics leave out rays repeated per material sample
+        assert work.extension_rays <= stats.extension_rays + W * H * 2 * 4 * 10
+        for rays, boxes, tris in ((work.primary_rays, work.primary_boxes, work.primary_triangles),
+                                  (work.extension_rays, work.extension_boxes, work.extension_triangles),
+                                  (work.shadow_rays, work.shadow_boxes, work.shadow_triangles)):
+            assert rays > 0 and 2 <= boxes / rays <= 2 * g.info().n_nodes and tris / rays <= g.info().n_triangles
 
 
 def test_materials_emissive_mix_and_environment():

@@ -1,5 +1,5 @@
-"""CPU tests of the host-side logic: scene generators, band partition, and the multi-rank gather
-path on the gloo backend (world size 2)."""
+"""CPU tests of the host-side logic: scene generators, the square order of the multi-GPU path, and the multi-rank
+gather on the gloo backend (world size 2)."""
 import os
 import socket
 import subprocess
@@ -36,34 +36,57 @@ def test_band_partition_covers_every_row_once():
                     assert 0 <= y0 < y1 <= H
                     seen[y0:y1] += 1
             assert np.all(seen == 1)
-            rows = [sum(y1 - y0 for y0, y1 in distributed.rank_bands(H, world, r)) for r in range(world)]
-            assert max(rows) == distributed.padded_rows(H, world)
-            if H >= world * 8:
-                assert max(rows) - min(rows) <= distributed.band_height(H, world)
+
+
+def _pattern(W, H):
+    ys = np.arange(H, dtype=np.float32)[:, None, None]
+    xs = np.arange(W, dtype=np.float32)[None, :, None]
+    cs = np.arange(3, dtype=np.float32)[None, None, :]
+    return (ys * 4096 + xs * 3 + cs + 1).astype(np.float32) * np.ones((H, W, 3), np.float32)
+
+
+def test_square_order_is_a_permutation_for_every_world_size():
+    """Cutting a frame into squares shared out over G ranks and writing the ranks' compact buffers back gives the frame
+    bit for bit, for G = 1, 2, 4, 8, whole frames and sub-tiles, squares that stick out of the tile included; every
+    pixel of the tile is owned exactly once; sizes are the ones the library reports."""
+    for (W, H, tile, T) in ((37, 53, None, 8), (64, 64, None, 32), (1920, 1080, None, 32), (100, 70, (10, 5, 93, 64), 16), (5, 3, None, 32)):
+        frame = _pattern(W, H)
+        st = abi.make_settings(W, H, tile=tile)
+        xs, ys, xe, ye = (0, 0, W, H) if tile is None else tile
+        for world in (1, 2, 4, 8):
+            bufs = [distributed.compact_from_frame(frame, st, T, r, world) for r in range(world)]
+            for r, b in enumerate(bufs):
+                assert b.size == distributed.tile_buffer_floats(st, T, r, world)
+            assert bufs[0].size == max(b.size for b in bufs)                 # rank 0's buffer is the largest: the gather's stride
+            assert sum(int((b.reshape(-1, 3)[:, 2] != 0).sum()) for b in bufs) == (xe - xs) * (ye - ys)   # each pixel once (values are > 0)
+            background = np.full((H, W, 3), -1.0, np.float32)
+            out = distributed.scatter_to_frame(bufs, st, T, background.copy())
+            assert np.array_equal(out[ys:ye, xs:xe], frame[ys:ye, xs:xe])
+            mask = np.ones((H, W), bool)
+            mask[ys:ye, xs:xe] = False
+            assert (out[mask] == -1.0).all()                                  # nothing outside the tile is written
 
 
 WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
 import numpy as np, torch, torch.distributed as dist
-from raytracer_amd import distributed
+from raytracer_amd import abi, distributed
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo")
-W, H = 37, 53
-def value(y0, y1):
-    ys = np.arange(y0, y1, dtype=np.float32)[:, None, None]
-    xs = np.arange(W, dtype=np.float32)[None, :, None]
-    cs = np.arange(3, dtype=np.float32)[None, None, :]
-    return (ys * 1000 + xs * 3 + cs).astype(np.float32) * np.ones((y1 - y0, W, 3), np.float32)
-def render_band(y0, y1, out):
-    out.copy_(torch.from_numpy(value(y0, y1)))
-frame = distributed.render_sharded(render_band, W, H, rank, world, torch.device("cpu"))
+W, H, T = 37, 53, 8
+ys = np.arange(H, dtype=np.float32)[:, None, None]
+xs = np.arange(W, dtype=np.float32)[None, :, None]
+cs = np.arange(3, dtype=np.float32)[None, None, :]
+frame = (ys * 1000 + xs * 3 + cs).astype(np.float32) * np.ones((H, W, 3), np.float32)
+st = abi.make_settings(W, H)
+local = torch.from_numpy(distributed.compact_from_frame(frame, st, T, rank, world))   # what this rank "rendered"
+got = distributed.gather_compact(local, st, T, rank, world)
 if rank == 0:
-    want = distributed.assemble_reference(H, W, world, value)
-    assert np.array_equal(frame.numpy(), want) and np.array_equal(want, value(0, H))
+    assert np.array_equal(got, frame)
     print("GATHER_OK")
 else:
-    assert frame is None
+    assert got is None
 dist.barrier()
 dist.destroy_process_group()
 """
