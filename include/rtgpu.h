@@ -333,6 +333,17 @@ typedef struct rtgpu_render_profile {
 int rtgpu_render_profile_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
                                 float* d_rgb_out, rtgpu_render_profile* profile, void* hip_stream);
 
+/* rtgpu_render_device without any allocation.  No counterpart in the reference: it is for callers that cannot allocate
+ * device memory while they run -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * The integrator's workspace is a fixed array of RTGPU_STATIC_WORKSPACE_BYTES inside the library (each GPU the library
+ * runs on holds it until the process ends), paths are rendered in batches that fit it, all work is enqueued on hip_stream
+ * and the call returns without waiting (the caller synchronises; no ray statistics).  Calls that overlap on one GPU share
+ * the array and race: one call at a time per GPU.  RTGPU_ERR_LIMIT when one pixel's geometry_aa * material_aa paths
+ * (about 140 bytes each) do not fit the array; n_gpus must be 0 or 1.  The image is bit-identical to rtgpu_render_device's. */
+#define RTGPU_STATIC_WORKSPACE_BYTES (64u << 20)
+int rtgpu_render_device_static(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                               float* d_rgb_out, void* hip_stream);
+
 /* PerspectiveCamera(fov) + setTransform (camera/PerspectiveCamera.cpp:7-19): fills *out from a
  * horizontal field of view in degrees and a row-major object->world 4x4. */
 int rtgpu_camera_from_transform(double fov_x_degrees, const double transform[16], rtgpu_camera* out);

@@ -30,7 +30,7 @@ EXPORTS = [
     "rtgpu_write_exr", "rtgpu_write_png",
     "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
     "rtgpu_comm_unique_id", "rtgpu_comm_create", "rtgpu_comm_destroy", "rtgpu_tile_buffer_floats", "rtgpu_render_tiles_device",
-    "rtgpu_gather_tiles_device", "rtgpu_scatter_tiles_device", "rtgpu_scene_replicate", "rtgpu_render_work_device", "rtgpu_render_profile_device",
+    "rtgpu_gather_tiles_device", "rtgpu_scatter_tiles_device", "rtgpu_scene_replicate", "rtgpu_render_work_device", "rtgpu_render_profile_device", "rtgpu_render_device_static",
 ]
 
 _lib = None
@@ -94,6 +94,7 @@ def lib():
     L.rtgpu_scatter_tiles_device.argtypes = [C.POINTER(abi.RenderSettings), C.c_int, C.c_int, vp, vp, vp]
     L.rtgpu_scene_replicate.argtypes = [vp, C.c_int, C.POINTER(vp)]
     L.rtgpu_render_profile_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp, C.POINTER(abi.RenderProfile), vp]
+    L.rtgpu_render_device_static.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp, vp]
     L.rtgpu_render_work_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), vp, C.POINTER(abi.RenderWork), vp]
     _lib = L
     return L
@@ -297,6 +298,11 @@ class Renderer:
         work = abi.RenderWork()
         _check(lib().rtgpu_render_work_device(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), C.byref(work), _stream_ptr(stream)))
         return work
+
+    def render_device_static(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, d_framebuffer, stream=None):
+        """rtgpu_render_device_static: enqueues the render on `stream` using the library's fixed workspace; allocates nothing and
+        does not wait."""
+        _check(lib().rtgpu_render_device_static(scene.handle, C.byref(cam), C.byref(settings), _ptr(d_framebuffer), _stream_ptr(stream)))
 
     def render_profile_device(self, scene: Scene, cam: abi.Camera, settings: abi.RenderSettings, d_framebuffer, stream=None) -> abi.RenderProfile:
         """The same frame, one batch at a time with HIP events around every launch: device time per stage."""

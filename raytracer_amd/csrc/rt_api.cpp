@@ -753,6 +753,20 @@ int rtgpu_render_device(const rtgpu_scene* scene, const rtgpu_camera* camera, co
     });
 }
 
+int rtgpu_render_device_static(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
+                               float* d_rgb_out, void* hip_stream)
+{
+    if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
+    if (!camera) return fail(RTGPU_ERR_NO_CAMERA, "No camera in scene.");
+    if (int rc = check_settings(settings)) return rc;
+    if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
+        return fail(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
+    if (!d_rgb_out) return fail(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null");
+    if (settings->n_gpus > 1) return fail(RTGPU_ERR_INVALID_ARGUMENT, "the static-workspace render runs on one device");
+    RT_HIP(hipSetDevice(scene->device));
+    return rt::guarded([&]() -> int { return rt::render_static(*scene, *camera, *settings, d_rgb_out, (hipStream_t)hip_stream); });
+}
+
 int rtgpu_render_profile_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
                                 float* d_rgb_out, rtgpu_render_profile* profile, void* hip_stream)
 {

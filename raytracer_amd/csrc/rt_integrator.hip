@@ -34,6 +34,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -1424,6 +1425,76 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     }
 #undef RT_TRY
     return hipSuccess;
+}
+
+// ---- the render that allocates nothing -----------------------------------------------------------------
+// For callers that cannot allocate device memory while they run (code under HIP graph capture, serving loops, harnesses
+// that forbid hipMalloc): the integrator's workspace is a fixed array inside the library's code object instead of a
+// hipMalloc'ed block, batches are sized to fit it, everything is enqueued on the caller's stream, and nothing is read back
+// (every pass is launched over the batch's full path count and finds its queue length on the device).
+namespace {
+
+static __device__ __align__(256) unsigned char scratch[RTGPU_STATIC_WORKSPACE_BYTES];
+
+constexpr int kMaxDevices = 64;
+void* g_scratchPtr[kMaxDevices] = {};
+std::mutex g_scratchMutex;
+
+// The array's address on `device` (every GPU holds its own copy at its own address); looked up once per device with that
+// device current.  In host code the array's name is only a handle for this look-up, never an address to hand to a kernel.
+hipError_t static_workspace(int device, void** out)
+{
+    std::lock_guard<std::mutex> lock(g_scratchMutex);
+    if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
+    if (!g_scratchPtr[device]) {
+        hipError_t e = hipSetDevice(device);
+        if (e != hipSuccess) return e;
+        void* ptr = nullptr;
+        e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        if (e != hipSuccess) return e;
+        g_scratchPtr[device] = ptr;
+    }
+    *out = g_scratchPtr[device];
+    return hipSuccess;
+}
+
+} // namespace
+
+int render_static(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* dRgb, hipStream_t stream)
+{
+    const SceneView& sv = scene.view;
+    Batch proto;
+    const uint64_t nPixelsTotal = call_pixels(st, nullptr, proto);
+    if (nPixelsTotal == 0) return RTGPU_OK;
+    const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
+    const uint64_t pathsPerPixel = (uint64_t)G * M;
+    // the largest batch whose workspace fits the array
+    auto bytes_for = [&](uint64_t pixels) { Pool probe{}; return pool_carve(probe, nullptr, pool_dims(sv, pixels * pathsPerPixel, pixels * G)); };
+    if (pathsPerPixel >= (1ull << 31) || bytes_for(1) > RTGPU_STATIC_WORKSPACE_BYTES)
+        return set_error(RTGPU_ERR_LIMIT, "geometry_aa * material_aa = " + std::to_string(pathsPerPixel) + " paths per pixel do not fit the " +
+                                              std::to_string(RTGPU_STATIC_WORKSPACE_BYTES >> 20) + " MiB static workspace");
+    uint64_t lo = 1, hi = std::min<uint64_t>(nPixelsTotal, ((1ull << 31) - 1) / pathsPerPixel);
+    while (lo < hi) {
+        const uint64_t mid = (lo + hi + 1) / 2;
+        if (bytes_for(mid) <= RTGPU_STATIC_WORKSPACE_BYTES) lo = mid;
+        else hi = mid - 1;
+    }
+    const uint64_t pixelsPerBatch = lo;
+    void* base = nullptr;
+    hipError_t e = static_workspace(scene.device, &base);
+    if (e != hipSuccess) return set_error(RTGPU_ERR_HIP, std::string("hipGetSymbolAddress(static workspace): ") + hipGetErrorString(e));
+    LaneRun ln;
+    ln.stream = stream;
+    pool_carve(ln.pool, (char*)base, pool_dims(sv, pixelsPerBatch * pathsPerPixel, pixelsPerBatch * G));
+    std::string err;
+    for (uint64_t start = 0; start < nPixelsTotal; start += pixelsPerBatch) {
+        Batch batch = proto;
+        batch.pixelStart = (uint32_t)start;
+        batch.nPixels = (uint32_t)std::min<uint64_t>(pixelsPerBatch, nPixelsTotal - start);
+        e = run_batch(sv, ln, cam, st, batch, dRgb, err);   // batches follow each other on the one stream, so they can share the workspace
+        if (e != hipSuccess) return set_error(RTGPU_ERR_HIP, err.empty() ? hipGetErrorString(e) : err);
+    }
+    return RTGPU_OK;
 }
 
 } // namespace rt

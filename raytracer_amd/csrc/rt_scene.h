@@ -80,6 +80,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                             float* dOut, rtgpu_render_stats* stats, uint64_t* work, hipStream_t stream, std::string& err,
                             rtgpu_render_profile* profile = nullptr);
 void destroy_multi(rtgpu_multi*);
+// rtgpu_render_device_static: the whole call enqueued on `stream`, workspace in the library's fixed device array.
+int render_static(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* dRgb, hipStream_t stream);
 // rtgpu_render over settings.n_gpus devices of this process (rt_multi.hip).
 int render_multi_entry(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* rgbOut, rtgpu_render_stats* stats);
 
