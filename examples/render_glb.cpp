@@ -131,7 +131,8 @@ int main(int argc, char** argv)
     namespace fs = std::filesystem;
     std::map<std::string, std::string> opt = {{"workdir", fs::current_path().string()}, {"scene", "scene.glb"}, {"width", "500"}, {"height", "500"}, {"xstart", "0"}, {"ystart", "0"},
                                               {"outputtype", "exr"}, {"output", "output"}, {"exposure", "-2.5"}, {"gamma", "2.2"}, {"aageometry", "4"}, {"aamaterial", "4"}, {"seed", "0"},
-                                              {"pmmode", "none"}, {"pmdepth", "0"}, {"pmfile", ""}, {"pmrayspointlamp", "10000000"}, {"pmraysarealamp", "10000000"}, {"perffci", ""}};
+                                              {"pmmode", "none"}, {"pmdepth", "0"}, {"pmfile", ""}, {"pmrayspointlamp", "10000000"}, {"pmraysarealamp", "10000000"}, {"perffci", ""},
+                                              {"gpus", "1"}};
     bool soupify = false, savePm = false, loadPm = false;
     std::vector<std::string> tileFilesToMerge;
     for (int i = 1; i < argc; ++i) {
@@ -146,7 +147,7 @@ int main(int argc, char** argv)
             while (i + 1 < argc && std::strncmp(argv[i + 1], "--", 2) != 0) tileFilesToMerge.push_back(argv[++i]);
             continue;
         }
-        if (a == "help") { std::printf("options: --workdir --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma --mergetiles --pmmode --pmdepth --pmrayspointlamp --pmraysarealamp --savepm --loadpm --pmfile\n"); return 0; }
+        if (a == "help") { std::printf("options: --workdir --scene --width --height --xstart --ystart --xend --yend --soupify --aageometry --aamaterial --seed --outputtype --output --exposure --gamma --mergetiles --pmmode --pmdepth --pmrayspointlamp --pmraysarealamp --savepm --loadpm --pmfile --gpus\n"); return 0; }
         if (opt.find(a) == opt.end() && a != "xend" && a != "yend") { std::fprintf(stderr, "unrecognised option '--%s'\n", a.c_str()); return -1; }
         if (i + 1 >= argc) { std::fprintf(stderr, "option --%s needs a value\n", a.c_str()); return -1; }
         opt[a] = argv[++i];
@@ -166,6 +167,10 @@ int main(int argc, char** argv)
     settings.geometryAAModifier = std::atoi(opt["aageometry"].c_str());
     settings.materialAAModifier = std::atoi(opt["aamaterial"].c_str());
     settings.seed = (uint32_t)std::strtoul(opt["seed"].c_str(), nullptr, 10);
+    // not an option of the reference (which runs one process per tile and merges TILE files): the frame's tile is shared out
+    // over that many GPUs inside rtgpu_render and gathered with RCCL
+    settings.gpus = std::atoi(opt["gpus"].c_str());
+    if (settings.gpus < 1 || (settings.gpus > 1 && settings.gpus > rtgpu_device_count())) { std::fprintf(stderr, "Invalid number of GPUs (%d present).\n", rtgpu_device_count()); return -1; }
     const std::string type = opt["outputtype"];
     if (type != "exr" && type != "png" && type != "ppm" && type != "tile") { std::fprintf(stderr, "Invalid output type: %s\n", type.c_str()); return -1; }
     // exe/Raytracer.cpp:142-155

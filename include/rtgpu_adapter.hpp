@@ -48,6 +48,8 @@ struct RenderSettings {
     int materialAAModifier = 32;
     int maxPathLength = 10; // renderer/Renderer.cpp:130
     uint32_t seed = 0;      // the reference seeds from std::random_device; here the image is reproducible
+    int gpus = 1;           // > 1: the tile is cut into squares shared out over that many GPUs of this process and gathered
+                            // with RCCL (the reference: one process per tile + --mergetiles, exe/Raytracer.cpp:260-277)
 };
 
 // utility/ProgressMonitor.h:8 without the duration argument
@@ -87,7 +89,12 @@ public:
         check(rtgpu_scene_set_photons(scene_, photons.data(), photons.size(), mode, depth));
     }
 
-    // Scene::traceRay (scene/renderable/Scene.cpp:14-17)
+    // Scene::traceRay (scene/renderable/Scene.cpp:14-17).  One ray per call costs a PCIe round trip and a kernel launch
+    // (tens of microseconds) whatever the ray: a caller shaped like the reference's shading code -- one testVisibility
+    // per light sample (material/NextEventEstimation.cpp:16,38,60), one traceRay per glossy bounce
+    // (material/GlossyMaterial.cpp:124) -- should collect its rays and use traceRays / testVisibilities below, which
+    // stream any number of rays through pinned buffers at PCIe speed; the integrator inside rtgpu_render never
+    // leaves the device for them at all.
     std::optional<rtgpu_hit> traceRay(const float origin[3], const float direction[3]) const
     {
         rtgpu_hit h;
@@ -108,6 +115,12 @@ public:
         return occluded != 0;
     }
 
+    // The batched form of testVisibility: occluded[i] = 1 when ray i hits something within maxT[i].
+    void testVisibilities(const float* origins, const float* directions, const float* maxT, uint64_t n, uint8_t* occluded) const
+    {
+        check(rtgpu_trace_any(scene_, origins, directions, maxT, n, occluded));
+    }
+
 private:
     rtgpu_scene* scene_ = nullptr;
 };
@@ -122,6 +135,7 @@ public:
                               ProgressMonitor progress = nullptr) const
     {
         rtgpu_render_settings st{};
+        st.n_gpus = rs.gpus;
         st.width = width;
         st.height = height;
         st.x_start = tile.xStart; st.y_start = tile.yStart; st.x_end = tile.xEnd; st.y_end = tile.yEnd;

@@ -205,6 +205,98 @@ namespace rt {
 int set_error(int code, const std::string& msg) { return fail(code, msg); }
 } // namespace rt
 
+// ---- the host-pointer entry points --------------------------------------------------------------------
+// Rays arrive in and results go back to ordinary (pageable) host arrays, so a batch crosses PCIe twice.  The batch is cut
+// into chunks; each chunk is copied into a pinned buffer by a host thread, sent to the device, traced and fetched back on
+// that thread's stream, and copied out of its pinned buffer -- several threads do this side by side, so the host copies,
+// the two DMA directions and the kernels of different chunks overlap.  Pinned and device buffers and the streams are made
+// once per scene and kept.
+namespace rt {
+
+struct HostPipe {
+    static constexpr uint64_t kChunk = 1ull << 18;      // rays per chunk
+    static constexpr size_t kInBytes = 28, kOutBytes = 20;   // per ray: origin + direction + limit in, hit record out
+    struct Slot {
+        char* pinIn = nullptr;
+        char* pinOut = nullptr;
+        char* devIn = nullptr;
+        char* devOut = nullptr;
+        hipStream_t stream = nullptr;
+    };
+    std::vector<Slot> slots;
+};
+
+void destroy_host_pipe(HostPipe* p)
+{
+    if (!p) return;
+    for (HostPipe::Slot& s : p->slots) {
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.pinIn) (void)hipHostFree(s.pinIn);
+        if (s.pinOut) (void)hipHostFree(s.pinOut);
+        if (s.devIn) (void)hipFree(s.devIn);
+        if (s.devOut) (void)hipFree(s.devOut);
+    }
+    delete p;
+}
+
+} // namespace rt
+
+namespace {
+
+hipError_t ensure_host_pipe(const rtgpu_scene& scene, size_t nSlots)
+{
+    using rt::HostPipe;
+    if (!scene.hostPipe) scene.hostPipe = new HostPipe();
+    HostPipe& hp = *scene.hostPipe;
+    while (hp.slots.size() < nSlots) {
+        HostPipe::Slot s;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.pinIn, HostPipe::kChunk * HostPipe::kInBytes);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&s.pinOut, HostPipe::kChunk * HostPipe::kOutBytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.devIn, HostPipe::kChunk * HostPipe::kInBytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.devOut, HostPipe::kChunk * HostPipe::kOutBytes);
+        hp.slots.push_back(s);   // kept even when incomplete: destroy_host_pipe frees what there is
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
+}
+
+// Runs `n` rays through the chunk pipeline.  fill(slot, first, m) copies the chunk's inputs into slot.pinIn and returns
+// the bytes to send; launch(slot, m) enqueues the kernel on slot.stream; drain(slot, first, m, outBytes) copies
+// slot.pinOut to the caller's array.
+template <typename Fill, typename Launch, typename Drain>
+int host_pipeline(const rtgpu_scene& scene, uint64_t n, size_t outBytesPerRay, const Fill& fill, const Launch& launch, const Drain& drain)
+{
+    using rt::HostPipe;
+    const uint64_t nChunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const size_t nThreads = (size_t)std::min<uint64_t>(nChunks, std::min<unsigned>(8u, std::max(1u, hw / 2)));
+    RT_HIP(ensure_host_pipe(scene, nThreads));
+    std::vector<hipError_t> errs(nThreads, hipSuccess);
+    auto worker = [&](size_t t) {
+        hipError_t e = hipSetDevice(scene.device);
+        HostPipe::Slot& slot = scene.hostPipe->slots[t];
+        for (uint64_t c = t; c < nChunks && e == hipSuccess; c += nThreads) {
+            const uint64_t first = c * HostPipe::kChunk, m = std::min(HostPipe::kChunk, n - first);
+            const size_t inBytes = fill(slot, first, m);
+            e = hipMemcpyAsync(slot.devIn, slot.pinIn, inBytes, hipMemcpyHostToDevice, slot.stream);
+            if (e == hipSuccess) e = launch(slot, m);
+            if (e == hipSuccess) e = hipMemcpyAsync(slot.pinOut, slot.devOut, m * outBytesPerRay, hipMemcpyDeviceToHost, slot.stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(slot.stream);
+            if (e == hipSuccess) drain(slot, first, m);
+        }
+        errs[t] = e;
+    };
+    std::vector<std::thread> threads;
+    for (size_t t = 1; t < nThreads; ++t) threads.emplace_back(worker, t);
+    worker(0);
+    for (std::thread& t : threads) t.join();
+    for (hipError_t e : errs) RT_HIP(e);
+    return RTGPU_OK;
+}
+
+} // namespace
+
 void rtgpu_scene::release()
 {
     (void)hipSetDevice(device);
@@ -212,6 +304,8 @@ void rtgpu_scene::release()
     multi = nullptr;
     rt::destroy_render_cache(renderCache);
     renderCache = nullptr;
+    rt::destroy_host_pipe(hostPipe);
+    hostPipe = nullptr;
     arrays.clear();
     const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
                           view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.envMap, view.kdPos, view.kdNormal, view.kdEnergy};
@@ -656,7 +750,6 @@ struct DevBuf {
     void* p = nullptr;
     ~DevBuf() { if (p) (void)hipFree(p); }
 };
-constexpr uint64_t kHostChunk = 1ull << 24; // rays per staged chunk of the host-pointer entry points
 } // namespace
 
 int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const float* dirs, uint64_t n, rtgpu_hit* out_hits)
@@ -665,19 +758,19 @@ int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const fl
     if (n == 0) return RTGPU_OK;
     if (!origins || !dirs || !out_hits) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/hit buffer");
     RT_HIP(hipSetDevice(scene->device));
-    const uint64_t cap = std::min(n, kHostChunk);
-    DevBuf dO, dD, dH;
-    RT_HIP(hipMalloc(&dO.p, cap * 12));
-    RT_HIP(hipMalloc(&dD.p, cap * 12));
-    RT_HIP(hipMalloc(&dH.p, cap * sizeof(rtgpu_hit)));
-    for (uint64_t b = 0; b < n; b += cap) {
-        const uint64_t m = std::min(cap, n - b);
-        RT_HIP(hipMemcpy(dO.p, origins + 3 * b, m * 12, hipMemcpyHostToDevice));
-        RT_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
-        RT_HIP(rt::launch_trace_closest(scene->view, (const float*)dO.p, (const float*)dD.p, m, (rtgpu_hit*)dH.p, nullptr, nullptr));
-        RT_HIP(hipMemcpy(out_hits + b, dH.p, m * sizeof(rtgpu_hit), hipMemcpyDeviceToHost));
-    }
-    return RTGPU_OK;
+    using rt::HostPipe;
+    return rt::guarded([&]() -> int {
+        return host_pipeline(*scene, n, sizeof(rtgpu_hit),
+            [&](HostPipe::Slot& s, uint64_t first, uint64_t m) -> size_t {
+                std::memcpy(s.pinIn, origins + 3 * first, m * 12);
+                std::memcpy(s.pinIn + m * 12, dirs + 3 * first, m * 12);
+                return (size_t)m * 24;
+            },
+            [&](HostPipe::Slot& s, uint64_t m) {
+                return rt::launch_trace_closest(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), m, (rtgpu_hit*)s.devOut, nullptr, s.stream);
+            },
+            [&](HostPipe::Slot& s, uint64_t first, uint64_t m) { std::memcpy(out_hits + first, s.pinOut, m * sizeof(rtgpu_hit)); });
+    });
 }
 
 int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float* dirs, const float* tmax, uint64_t n, uint8_t* out_occluded)
@@ -686,21 +779,21 @@ int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float*
     if (n == 0) return RTGPU_OK;
     if (!origins || !dirs || !tmax || !out_occluded) return fail(RTGPU_ERR_INVALID_ARGUMENT, "null ray/result buffer");
     RT_HIP(hipSetDevice(scene->device));
-    const uint64_t cap = std::min(n, kHostChunk);
-    DevBuf dO, dD, dT, dR;
-    RT_HIP(hipMalloc(&dO.p, cap * 12));
-    RT_HIP(hipMalloc(&dD.p, cap * 12));
-    RT_HIP(hipMalloc(&dT.p, cap * 4));
-    RT_HIP(hipMalloc(&dR.p, cap));
-    for (uint64_t b = 0; b < n; b += cap) {
-        const uint64_t m = std::min(cap, n - b);
-        RT_HIP(hipMemcpy(dO.p, origins + 3 * b, m * 12, hipMemcpyHostToDevice));
-        RT_HIP(hipMemcpy(dD.p, dirs + 3 * b, m * 12, hipMemcpyHostToDevice));
-        RT_HIP(hipMemcpy(dT.p, tmax + b, m * 4, hipMemcpyHostToDevice));
-        RT_HIP(rt::launch_trace_any(scene->view, (const float*)dO.p, (const float*)dD.p, (const float*)dT.p, m, (uint8_t*)dR.p, nullptr));
-        RT_HIP(hipMemcpy(out_occluded + b, dR.p, m, hipMemcpyDeviceToHost));
-    }
-    return RTGPU_OK;
+    using rt::HostPipe;
+    return rt::guarded([&]() -> int {
+        return host_pipeline(*scene, n, 1,
+            [&](HostPipe::Slot& s, uint64_t first, uint64_t m) -> size_t {
+                std::memcpy(s.pinIn, origins + 3 * first, m * 12);
+                std::memcpy(s.pinIn + m * 12, dirs + 3 * first, m * 12);
+                std::memcpy(s.pinIn + m * 24, tmax + first, m * 4);
+                return (size_t)m * 28;
+            },
+            [&](HostPipe::Slot& s, uint64_t m) {
+                return rt::launch_trace_any(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), (const float*)(s.devIn + m * 24), m,
+                                            (uint8_t*)s.devOut, s.stream);
+            },
+            [&](HostPipe::Slot& s, uint64_t first, uint64_t m) { std::memcpy(out_occluded + first, s.pinOut, m); });
+    });
 }
 
 static int check_settings(const rtgpu_render_settings* st)

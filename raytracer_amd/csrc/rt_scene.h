@@ -13,6 +13,8 @@
 namespace rt {
 struct RenderCache;                       // streams, events and workspaces the integrator keeps between calls
 void destroy_render_cache(RenderCache*);
+struct HostPipe;                          // pinned / device staging buffers and streams of the host-pointer entry points
+void destroy_host_pipe(HostPipe*);
 // One device array of a scene: where its pointer sits inside the SceneView and how many bytes it holds (what a copy of
 // the scene onto another device has to move).
 struct SceneArray {
@@ -35,6 +37,7 @@ struct rtgpu_scene {
     std::vector<rtgpu_photon> photons;   // the photon map's photons in emission order (host copy)
     std::vector<rt::SceneArray> arrays;  // every device array `view` points to
     mutable rt::RenderCache* renderCache = nullptr;
+    mutable rt::HostPipe* hostPipe = nullptr;
     mutable rtgpu_multi* multi = nullptr;
     void release();
     // Registers / replaces the array behind a pointer member of `view`.

@@ -49,6 +49,9 @@ struct StealLds : StealCounters<COUNT> {
     int giveList[64];
 };
 
+// t must be >= +0 or +inf: the bit pattern of -0 (what Triangle::intersect returns for a ray that starts exactly in the
+// triangle's plane: -0 < 0 is false, so the reference accepts it, math/Triangle.h:60-66) would order above +inf.  Callers
+// pass t + 0.0f, which is t for every other value and +0 for -0.
 __device__ __forceinline__ unsigned long long pack_hit(float t, uint32_t id)
 {
     return ((unsigned long long)__float_as_uint(t) << 32) | id;
@@ -212,7 +215,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 if (ANY) {
                     if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
                 } else if (t <= tlim) {
-                    const unsigned long long mine = pack_hit(t, sv.triIds[slot]);
+                    const unsigned long long mine = pack_hit(t + 0.0f, sv.triIds[slot]);   // -0 (a ray that starts in the triangle's plane) as +0
                     const unsigned long long old = atomicMin(&L.best[owner], mine);
                     if (mine < old && L.best[owner] == mine) L.paySlot[owner] = slot;
                 }
@@ -452,7 +455,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     if (ANY) {
                         if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
                     } else if (t <= tlim) {
-                        const unsigned long long mine = pack_hit(t, keyBase + sv.triIds[slot]);
+                        const unsigned long long mine = pack_hit(t + 0.0f, keyBase + sv.triIds[slot]);   // -0 as +0, see pack_hit
                         const unsigned long long old = atomicMin(&L.best[owner], mine);
                         if (mine < old && L.best[owner] == mine) { L.paySlot[owner] = slot; L.payInst[owner] = curInst; }
                     }
