@@ -150,7 +150,9 @@ typedef struct rtgpu_scene_desc {
     uint32_t n_area_lights;
     int32_t has_environment; /* 0: none; 1: ColorEnvironment (material/environment/ColorEnvironment.cpp:6-9), radiance =
                               * env_color * env_intensity; 2: ImageMapEnvironment (ImageMapEnvironment.cpp:15-23), radiance =
-                              * the texel of env_map at the direction's longitude / latitude * env_intensity */
+                              * the texel of env_map at the direction's longitude / latitude * env_intensity; 3: SkyEnvironment
+                              * (material/environment/SkyEnvironment.cpp:3-10), a fixed blend of sky blue and white by the direction's
+                              * height (no parameters; no loader of the reference creates one) */
     float env_color[3];
     double env_intensity;
     const rtgpu_directional_light* directional_lights; /* may be null when n_directional_lights == 0 */

@@ -624,7 +624,7 @@ struct orc_scene {
     std::vector<rtgpu_directional_light> dirLights;
     struct Tex { std::vector<uint8_t> rgba; uint32_t width, height; double gamma; };
     std::vector<Tex> textures;
-    int hasEnv = 0;   // 0 none, 1 ColorEnvironment, 2 ImageMapEnvironment
+    int hasEnv = 0;   // 0 none, 1 ColorEnvironment, 2 ImageMapEnvironment, 3 SkyEnvironment
     RGBf envRadiance; // color * intensity, ColorEnvironment.cpp:6-9
     std::vector<float> envMap;   // Texture<float>: RGBA, rows top to bottom
     uint32_t envW = 0, envH = 0;
@@ -1701,6 +1701,10 @@ bool sample_path(RenderCtx& R, std::vector<TransportNode>& path, int startIdx, i
 // outside the image (the reference would read past it: straight down, the seam) are clamped; NaN reads column / row 0.
 RGBf env_radiance(const orc_scene& S, V3 dir)
 {
+    if (S.hasEnv == 3) {   // SkyEnvironment::getRadiance, material/environment/SkyEnvironment.cpp:3-10
+        const float t = 0.5f * (dir.y + 1.0f);
+        return rgb_add(rgb_scale_f(RGBf{0.5f, 0.7f, 1.0f}, t), rgb_scale_f(RGBf{1.0f, 1.0f, 1.0f}, 1.0f - t));
+    }
     if (S.hasEnv != 2) return S.envRadiance;
     const float latitude = std::asin(dir.y);
     const float cl = std::cos(latitude);

@@ -173,6 +173,7 @@ class SceneData:
     textures: List[tuple] = field(default_factory=list)       # ((h, w, 4) uint8 pixels, gamma)
     env: Optional[tuple] = None                               # (color3, intensity)
     env_map: Optional[tuple] = None                           # ((height, width, 4) float32 texels, intensity): an image-map environment
+    sky: bool = False                                         # SkyEnvironment (no parameters)
 
     def n_triangles(self) -> int:
         return int(sum(m.indices.shape[0] for m in self.meshes))
@@ -281,6 +282,8 @@ class PackedScene:
             d.has_environment = 1
             d.env_color[:] = [float(x) for x in scene.env[0]]
             d.env_intensity = float(scene.env[1])
+        if scene.sky:
+            d.has_environment = 3
         if scene.env_map is not None:
             texels = np.ascontiguousarray(scene.env_map[0], dtype=np.float32)
             if texels.ndim != 3 or texels.shape[2] != 4:

@@ -112,7 +112,7 @@ int validate(const rtgpu_scene_desc* d)
         if (!affine(id.transform) || !affine(id.inverse))
             return fail(RTGPU_ERR_INVALID_ARGUMENT, "instance transforms must be affine (last row 0 0 0 1)");
     }
-    if (d->has_environment < 0 || d->has_environment > 2) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown environment type");
+    if (d->has_environment < 0 || d->has_environment > 3) return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown environment type");
     if (d->has_environment == 2) {
         // Texture's constructor checks the buffer size (material/Texture.h:18-21)
         if (!d->env_map || d->env_map_width == 0 || d->env_map_height == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "environment map without pixels");

@@ -15,6 +15,7 @@ struct RGBf {
     float r, g, b;
 };
 __device__ __forceinline__ RGBf rgb(float r, float g, float b) { return RGBf{r, g, b}; }
+__device__ __forceinline__ RGBf rgb_add(RGBf a, RGBf b) { return RGBf{a.r + b.r, a.g + b.g, a.b + b.b}; } // RGB::operator+, film/RGB.h:93-105
 __device__ __forceinline__ RGBf rgb_mul(RGBf a, RGBf b) { return RGBf{a.r * b.r, a.g * b.g, a.b * b.b}; }
 __device__ __forceinline__ RGBf rgb_scale_f(RGBf a, float s) { return RGBf{a.r * s, a.g * s, a.b * s}; }                                  // RGB::scale(float), film/RGB.h:49-52
 __device__ __forceinline__ RGBf rgb_scale_d(RGBf a, double s) { return RGBf{(float)(a.r * s), (float)(a.g * s), (float)(a.b * s)}; }       // RGB::scale(double), film/RGB.h:44-47
@@ -296,6 +297,11 @@ __device__ __forceinline__ RGBf emission_lookup(const SceneView& sv, uint32_t te
 // clamped to it; a direction along the y axis (0 / 0 in the longitude) reads column 0.
 __device__ __forceinline__ RGBf env_radiance(const SceneView& sv, F3 dir)
 {
+    if (sv.hasEnv == 3) {
+        // SkyEnvironment::getRadiance (material/environment/SkyEnvironment.cpp:3-10): a vertical blend of a sky colour and white
+        const float t = 0.5f * (dir.y + 1.0f);
+        return rgb_add(rgb_scale_f(rgb(0.5f, 0.7f, 1.0f), t), rgb_scale_f(rgb(1.0f, 1.0f, 1.0f), 1.0f - t));
+    }
     if (sv.hasEnv != 2) return rgb(sv.envRadiance[0], sv.envRadiance[1], sv.envRadiance[2]);
     const float latitude = asinf(dir.y);
     const float cl = cosf(latitude);
@@ -410,7 +416,6 @@ __device__ __forceinline__ bool mat_has_variance(const SceneView& sv, uint32_t m
     return mat_variance_at<4>(sv, mi, normal, incomingDir, diffuseReadsMap);
 }
 
-__device__ __forceinline__ RGBf rgb_add(RGBf a, RGBf b) { return RGBf{a.r + b.r, a.g + b.g, a.b + b.b}; } // RGB::operator+, film/RGB.h:93-105
 // RGB::pow(double), film/RGB.h:85-88
 __device__ __forceinline__ RGBf rgb_pow_d(RGBf a, double power) { return RGBf{(float)pow((double)a.r, power), (float)pow((double)a.g, power), (float)pow((double)a.b, power)}; }
 

@@ -496,8 +496,8 @@ def glass_scene(view="room"):
 def sun_scene(lights="sun+point"):
     """Open scene under a directional light (light/DirectionalLight.h): a diffuse floor, a diffuse and a
     rough glossy sphere, a sky-coloured environment.  lights: "sun" (directional only), "sun+point"
-    (two light types), "all" (point + area + two directional lights) or "sky-map" (no lamp at all: an image-map
-    environment lights the scene)."""
+    (two light types), "all" (point + area + two directional lights), "sky-map" (no lamp at all: an image-map
+    environment lights the scene) or "sky" (the same under the SkyEnvironment gradient)."""
     parts = [(*grid_quad((-4, 0, -4), (0, 0, 8), (8, 0, 0), 4, 4), 0)]
     us = uv_sphere(16, 8)
     parts.append((us.vertices.astype(np.float64) * 0.8 + np.array([-1.0, 0.8, 0.3]), us.indices, 1))
@@ -515,7 +515,10 @@ def sun_scene(lights="sun+point"):
         sc.area_lights = [((-1.0, 3.5, -1.0), (1.0, 3.5, -1.0), (0.0, 3.5, 1.0), (1.0, 0.9, 0.8), 80.0)]
         d2 = np.array([0.6, -0.7, 0.4]); d2 /= np.linalg.norm(d2)
         sc.directional_lights.append((tuple(d2), 0.0, (0.3, 0.4, 1.0), 0.8))
-    if lights == "sky-map":
+    if lights == "sky":
+        sc.sky = True            # SkyEnvironment lights the scene, no lamp at all
+        sc.directional_lights = []
+    elif lights == "sky-map":
         # an image-map environment: smooth sky gradient with a few very bright texels (a sun) and random detail
         rng = np.random.RandomState(8)
         h, w = 32, 64
@@ -527,6 +530,8 @@ def sun_scene(lights="sun+point"):
         sc.directional_lights = []
     else:
         sc.env = ((0.25, 0.35, 0.5), 1.0)
+    if lights == "sky":
+        sc.env = None
     cam_m = look_at((0.3, 2.2, 5.0), (0.0, 0.6, 0.0))
     return sc, cam_m, 0.8
 

@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-"""Condenses gpurun_out/prof_<tag>/ (written by scripts/gpu_profile.sh) into tracked files under
-profiles/: the kernel-stats CSV, a per-launch PMC summary of the dominant kernel and the HBM
-traffic figure bench.py reports as roofline.traffic.
+"""Condenses gpurun_out/prof_<tag>/ (written by scripts/gpu_profile.sh) into tracked files under profiles/:
+<tag>_bench_kernel_stats.csv / <tag>_c2_kernel_stats.csv (rocprofv3 --kernel-trace --stats) and <tag>_pmc_summary.json,
+the per-frame (headline trace stage) and per-launch (configs[1] kernels) counter figures bench.py quotes beside its
+live numbers.
 
-HBM bytes per launch = 2 x FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE tallies
-128-B requests at 64 B, WRITE_SIZE is exact.  The x2 is calibrated for wide streaming reads; for
-this kernel's 16-B gathers it is an upper bound.
+HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, WRITE_SIZE
+is exact.  The x2 is calibrated for wide streaming reads; for these kernels' 16-B gathers it is an upper bound.
+VALU issue share = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz).
 """
 import collections
 import csv
@@ -13,55 +14,92 @@ import glob
 import json
 import os
 import shutil
+import subprocess
 import sys
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
-KERNEL = "trace_closest_steal_kernel<false>"
 
 
-def main():
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r01"
-    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
-    dst = os.path.join(ROOT, "profiles")
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
-    shutil.copy(stats, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
-    trace = glob.glob(os.path.join(src, "trace", "*", "*_kernel_trace.csv"))[0]
-    with open(trace) as f, open(os.path.join(dst, tag + "_bench_kernel_trace_trace_closest.csv"), "w") as g:
-        rd = csv.DictReader(f)
-        wr = csv.writer(g)
-        wr.writerow(["Kernel_Name", "Start_Timestamp", "End_Timestamp", "DurationNs", "Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count"])
-        for r in rd:
-            if "rt::" in r["Kernel_Name"]:
-                wr.writerow([r["Kernel_Name"].split("(")[0], r["Start_Timestamp"], r["End_Timestamp"],
-                             int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), r.get("Grid_Size", r.get("Grid_Size_X", "")),
-                             r.get("Workgroup_Size", r.get("Workgroup_Size_X", "")), r.get("LDS_Block_Size", ""),
-                             r.get("VGPR_Count", ""), r.get("SGPR_Count", "")])
-    summary = {"kernel": KERNEL, "per_launch": {}}
-    avg_ns = None
-    for r in csv.DictReader(open(stats)):
-        if KERNEL in r["Name"]:
-            avg_ns = float(r["AverageNs"])
-            summary["kernel_trace"] = {"calls": int(r["Calls"]), "average_ns": avg_ns, "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
-    for d in sorted(glob.glob(os.path.join(src, "pmc_*"))):
+def counters(dirs, kernel, split=None):
+    """Sums (per run) or lists (split = launches per group) the counter values of `kernel` over the runs in `dirs`."""
+    out = {}
+    for d in dirs:
         files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)
         for r in csv.DictReader(open(files[0])):
-            if KERNEL in r["Kernel_Name"]:
+            if kernel in r["Kernel_Name"]:
                 acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in acc.items():
-            summary["per_launch"][k] = {"mean": sum(v) / len(v), "min": min(v), "max": max(v), "launches": len(v)}
-    pl = summary["per_launch"]
-    if "FETCH_SIZE" in pl and "WRITE_SIZE" in pl:
-        hbm = (2.0 * pl["FETCH_SIZE"]["mean"] + pl["WRITE_SIZE"]["mean"]) * 1024.0
-        summary["hbm_bytes_per_launch"] = hbm
-        json.dump({"kernel": KERNEL, "hbm_bytes_per_launch": hbm,
-                   "fetch_size_kib": pl["FETCH_SIZE"]["mean"], "write_size_kib": pl["WRITE_SIZE"]["mean"],
-                   "formula": "(2*FETCH_SIZE + WRITE_SIZE) * 1024; FETCH_SIZE doubled per the gfx950 correction (upper bound for 16-B gathers)",
-                   "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate runs of bench.py --steps 5 --warmup 1 --no-cpu-baseline (%s)" % tag},
-                  open(os.path.join(dst, "traffic_trace_closest.json"), "w"), indent=1)
+            out[k] = v
+    return out
+
+
+def kernel_time(stats_csv, kernel):
+    for r in csv.DictReader(open(stats_csv)):
+        if kernel in r["Name"]:
+            return {"calls": int(r["Calls"]), "average_ns": float(r["AverageNs"]), "total_ns": float(r["TotalDurationNs"]),
+                    "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
+    return None
+
+
+def derived(c, seconds):
+    o = {}
+    if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+        o["fetch_size_kib"], o["write_size_kib"] = c["FETCH_SIZE"], c["WRITE_SIZE"]
+        o["hbm_bytes"] = (2.0 * c["FETCH_SIZE"] + c["WRITE_SIZE"]) * 1024.0
+        if seconds:
+            o["hbm_GBps"] = o["hbm_bytes"] / seconds / 1e9
+    if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+        o["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
+    for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY"):
+        if k in c:
+            o[k] = c[k]
+    if "SQ_INSTS_VALU" in c and seconds:
+        o["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (seconds * 2.4e9)
+    if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
+        o["wait_any_share_of_wave_cycles"] = c["SQ_WAIT_ANY"] / max(1.0, c["SQ_WAVE_CYCLES"])
+    return o
+
+
+def main():
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
+    src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+    dst = os.path.join(ROOT, "profiles")
+    summary = {"tag": tag, "commit": subprocess.run(["git", "rev-parse", "--short", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip(),
+               "commands": {"headline": "RTGPU_RENDER_LANES=1 rocprofv3 [--kernel-trace --stats | --pmc <group>] -- python3 bench.py --no-cpu-baseline --no-extras --no-roofline "
+                                        "(--steps 3 --warmup 1 for the trace, --steps 1 --warmup 0 for counters)",
+                            "configs[1]": "rocprofv3 [...] -- python3 scripts/prof_c2.py (6 launches on primary rays, then 6 on bounce rays)"}}
+    # ---- headline frame: trace_stage_kernel, per frame
+    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
+    kt = kernel_time(stats, "trace_stage_kernel")
+    frames_traced = 4   # --steps 3 --warmup 1
+    c = {k: sum(v) for k, v in counters(sorted(glob.glob(os.path.join(src, "pmc_head_*"))), "trace_stage_kernel").items()}
+    head = {"kernel": "trace_stage_kernel<kTraceSingle>", "kernel_trace": kt}
+    if kt:
+        head["launches_per_frame"] = kt["calls"] / frames_traced
+        head["trace_stage_ms_per_frame"] = kt["total_ns"] / frames_traced / 1e6
+        head.update(derived(c, kt["total_ns"] / frames_traced / 1e9))
+        if "hbm_bytes" in head:
+            head["hbm_bytes_per_frame"] = head.pop("hbm_bytes")
+    summary["headline_trace_stage"] = head
+    # ---- configs[1]: the closest-hit kernel, launches 0..5 primary rays, 6..11 bounce rays
+    stats2 = glob.glob(os.path.join(src, "trace_c2", "*", "*_kernel_stats.csv"))[0]
+    shutil.copy(stats2, os.path.join(dst, tag + "_c2_kernel_stats.csv"))
+    trace2 = glob.glob(os.path.join(src, "trace_c2", "*", "*_kernel_trace.csv"))[0]
+    durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace2)) if "trace_closest_steal_kernel" in r["Kernel_Name"]]
+    lists = counters(sorted(glob.glob(os.path.join(src, "pmc_c2_*"))), "trace_closest_steal_kernel")
+    for name, sl in (("c2_primary", slice(1, 6)), ("c2_bounce", slice(7, 12))):
+        sec = sum(durs[sl]) / max(1, len(durs[sl])) / 1e9 if len(durs) >= 12 else None
+        c = {k: sum(v[sl]) / max(1, len(v[sl])) for k, v in lists.items() if len(v) >= 12}
+        e = {"kernel": "trace_closest_steal_kernel<false>", "kernel_trace_average_ns": sec * 1e9 if sec else None}
+        e.update(derived(c, sec))
+        if "hbm_bytes" in e:
+            e["hbm_bytes_per_launch"] = e.pop("hbm_bytes")
+        summary[name] = e
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

@@ -1,15 +1,21 @@
 #!/bin/bash
-# Refreshes the profile evidence of the bench workload on the GPU box: kernel trace + stats, then
-# one PMC pass per counter group.  Outputs under gpurun_out/prof_<tag>/.
+# Refreshes the profile evidence on the GPU box: kernel trace + stats of the headline frame (one batch in flight, like
+# the profiling render bench.py takes its kernel time from), then one rocprofv3 --pmc pass per counter group over the
+# headline frame and over the configs[1] kernels.  Outputs under gpurun_out/prof_<tag>/; scripts/collect_profiles.py
+# condenses them into profiles/.
 set -o pipefail
-tag=${1:-r01}
+tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
 mkdir -p "$out"
 export TMPDIR=/tmp
+export RTGPU_RENDER_LANES=1
 cd "$(dirname "$0")/.." || exit 1
-timeout -k 10 240 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- python3 bench.py --steps 20 --no-cpu-baseline --no-frame > "$out/bench_trace.log" 2>&1 || exit 1
-timeout -s KILL 180 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-frame > "$out/bench_fetch.log" 2>&1 || exit 1
-timeout -s KILL 180 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-frame > "$out/bench_write.log" 2>&1 || exit 1
-timeout -s KILL 180 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d "$out/pmc_l2" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-frame > "$out/bench_l2.log" 2>&1 || exit 1
-timeout -s KILL 180 rocprofv3 --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_BUSY_CYCLES SQ_INSTS_LDS SQ_WAIT_INST_ANY --output-format csv -d "$out/pmc_sq" -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-frame > "$out/bench_sq.log" 2>&1 || exit 1
+HEAD="python3 bench.py --no-cpu-baseline --no-extras --no-roofline"
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $HEAD --steps 3 --warmup 1 > "$out/bench_trace.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c2" -- python3 scripts/prof_c2.py > "$out/c2_trace.log" 2>&1 || exit 1
+for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"; do
+    name=$(echo "$group" | cut -d' ' -f1)
+    timeout -s KILL 240 rocprofv3 --pmc $group --output-format csv -d "$out/pmc_head_$name" -- $HEAD --steps 1 --warmup 0 > "$out/bench_$name.log" 2>&1 || exit 1
+    timeout -s KILL 200 rocprofv3 --pmc $group --output-format csv -d "$out/pmc_c2_$name" -- python3 scripts/prof_c2.py > "$out/c2_$name.log" 2>&1 || exit 1
+done
 echo done

@@ -253,7 +253,7 @@ def rel_rmse(a, b):
 
 @pytest.mark.parametrize("name,G,M,W,H", [("box", 4, 4, 48, 36), ("box", 16, 16, 32, 24), ("mirror", 4, 16, 40, 30), ("c1", 4, 8, 80, 60), ("c1-meshes", 4, 8, 80, 60),
                                           ("coat", 4, 8, 64, 48), ("coat", 9, 4, 40, 30),
-                                          ("textured", 4, 4, 64, 48), ("bumps", 4, 8, 64, 48), ("bumps-plain", 4, 8, 64, 48), ("bumps-nouv", 2, 8, 48, 36), ("glass", 4, 8, 64, 48), ("glass", 2, 32, 40, 30), ("glass-pane", 2, 16, 40, 30), ("sun", 4, 4, 64, 48), ("sun+point", 4, 8, 48, 36), ("all", 9, 4, 48, 36), ("sky-map", 4, 8, 64, 48)])
+                                          ("textured", 4, 4, 64, 48), ("bumps", 4, 8, 64, 48), ("bumps-plain", 4, 8, 64, 48), ("bumps-nouv", 2, 8, 48, 36), ("glass", 4, 8, 64, 48), ("glass", 2, 32, 40, 30), ("glass-pane", 2, 16, 40, 30), ("sun", 4, 4, 64, 48), ("sun+point", 4, 8, 48, 36), ("all", 9, 4, 48, 36), ("sky-map", 4, 8, 64, 48), ("sky", 4, 8, 64, 48)])
 def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
     """The oracle and the GPU integrator draw the same counter-based random numbers, so images agree to
     float rounding (forward throughput vs. the reference's backward evaluation; device vs. host
@@ -277,7 +277,7 @@ def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
         sc, cam_m, yfov = scenes.textured_scene(normal_maps=True, plain_mesh=True, drop_texcoords=True)
     elif name == "textured":  # albedo maps (wrapping, negative coordinates, gamma) and an emission map
         sc, cam_m, yfov = scenes.textured_scene()
-    elif name in ("sun", "sun+point", "all", "sky-map"):  # directional lights, every combination of light types, environment
+    elif name in ("sun", "sun+point", "all", "sky-map", "sky"):  # directional lights, every combination of light types, environment
         sc, cam_m, yfov = scenes.sun_scene(name)
     else:
         sc, cam_m, yfov = scenes.box_scene(with_mirror=(name == "mirror"))

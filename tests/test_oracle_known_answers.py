@@ -544,3 +544,31 @@ def test_image_map_environment_is_read_at_the_longitude_and_latitude_of_the_ray(
     cam = oracle.camera_from_transform(1.0, scenes.look_at((0, 0, 0), (1.0, 0.0, 0.0)))
     img, _ = S.render(cam, abi.make_settings(1, 1, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER))
     assert np.allclose(img[0, 0], texels[h // 2, w // 2, :3] * 2.5, rtol=1e-6)
+
+
+def test_sky_environment_blends_by_the_height_of_the_direction():
+    """SkyEnvironment::getRadiance (material/environment/SkyEnvironment.cpp:3-10): t = (y + 1) / 2 of the ray's direction,
+    radiance = (0.5, 0.7, 1.0) * t + (1, 1, 1) * (1 - t): white straight down, the sky colour straight up, their mean at
+    the horizon.  A camera in an empty scene sees exactly that per pixel."""
+    from raytracer_amd.abi import MAT_DIFFUSE, InstanceData, MaterialData, MeshData, SceneData
+    sc = SceneData()
+    v = np.array([[1e6, 1e6, 1e6], [1e6 + 1, 1e6, 1e6], [1e6, 1e6 + 1, 1e6]], np.float32)
+    sc.meshes = [MeshData(v, np.tile(np.array([[0, 0, 1]], np.float32), (3, 1)), np.array([[0, 1, 2]], np.uint32))]
+    sc.materials = [MaterialData(MAT_DIFFUSE, (0.5, 0.5, 0.5))]
+    sc.instances = [InstanceData(0, 0, np.eye(4), np.eye(4))]
+    sc.sky = True
+    S = oracle.OracleScene(sc)
+    st = abi.make_settings(16, 16, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    for target in ((1.0, 0.4, 0.2), (0.1, 1.0, -0.2), (-0.3, -1.0, 0.5)):
+        cam = oracle.camera_from_transform(90.0, scenes.look_at((0, 0, 0), target))
+        img, _ = S.render(cam, st)
+        _, d = oracle.generate_primary(cam, st)
+        t = (np.float32(0.5) * (d[:, 1] + np.float32(1.0))).reshape(16, 16, 1)
+        want = np.array([0.5, 0.7, 1.0], np.float32) * t + np.float32(1.0) * (np.float32(1.0) - t)
+        assert np.array_equal(img, want.astype(np.float32))
+    one = abi.make_settings(1, 1, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    up, _ = S.render(oracle.camera_from_transform(1.0, scenes.look_at((0, 0, 0), (0, 1, 0), up=(0, 0, 1))), one)
+    down, _ = S.render(oracle.camera_from_transform(1.0, scenes.look_at((0, 0, 0), (0, -1, 0), up=(0, 0, 1))), one)
+    level, _ = S.render(oracle.camera_from_transform(1.0, scenes.look_at((0, 0, 0), (1, 0, 0))), one)
+    assert np.allclose(up[0, 0], (0.5, 0.7, 1.0), atol=1e-6) and np.allclose(down[0, 0], (1, 1, 1), atol=1e-6)
+    assert np.allclose(level[0, 0], (0.75, 0.85, 1.0), atol=1e-6)
