@@ -329,4 +329,62 @@ BuiltTree build_tree(const PrimBox* boxes, uint32_t n, const BuildParams& params
     return tree;
 }
 
+namespace {
+
+struct Collapser {
+    const std::vector<Node64>& in;
+    std::vector<Node128>& out;
+    uint32_t depth4 = 0;
+    struct Child { const float* lo; const float* hi; int32_t ref; };
+    static bool empty_box(const float* lo, const float* hi) { return lo[0] > hi[0] || lo[1] > hi[1] || lo[2] > hi[2]; }
+    int32_t emit(int32_t i, uint32_t depth)
+    {
+        const int32_t idx = (int32_t)out.size();
+        out.emplace_back();
+        depth4 = std::max(depth4, depth + 1);
+        const Node64& n = in[(size_t)i];
+        Child kids[4];
+        int nk = 0;
+        const Child two[2] = {{n.lo0, n.hi0, n.c0}, {n.lo1, n.hi1, n.c1}};
+        for (const Child& c : two) {
+            if (empty_box(c.lo, c.hi)) continue;          // the padding child of a single-leaf tree
+            if (c.ref >= 0) {
+                const Node64& g = in[(size_t)c.ref];
+                if (!empty_box(g.lo0, g.hi0)) kids[nk++] = Child{g.lo0, g.hi0, g.c0};
+                if (!empty_box(g.lo1, g.hi1)) kids[nk++] = Child{g.lo1, g.hi1, g.c1};
+            } else {
+                kids[nk++] = c;
+            }
+        }
+        for (int k = 0; k < 4; ++k) {
+            Node128& d = out[(size_t)idx];
+            if (k < nk) {
+                for (int a = 0; a < 3; ++a) { d.box[k][a] = kids[k].lo[a]; d.box[k][3 + a] = kids[k].hi[a]; }
+            } else {
+                for (int a = 0; a < 3; ++a) { d.box[k][a] = FLT_MAX; d.box[k][3 + a] = -FLT_MAX; }
+                d.c[k] = kEmptyChild;
+            }
+            d.pad[k] = 0;
+        }
+        for (int k = 0; k < nk; ++k) {
+            const int32_t r = kids[k].ref >= 0 ? emit(kids[k].ref, depth + 1) : kids[k].ref;
+            out[(size_t)idx].c[k] = r;
+        }
+        return idx;
+    }
+};
+
+} // namespace
+
+std::vector<Node128> collapse_tree4(const std::vector<Node64>& binary, uint32_t& depth4)
+{
+    std::vector<Node128> out;
+    out.reserve(binary.size() / 2 + 1);
+    Collapser c{binary, out};
+    c.emit(0, 0);
+    depth4 = c.depth4;
+    out.shrink_to_fit();
+    return out;
+}
+
 } // namespace rt

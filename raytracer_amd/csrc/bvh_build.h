@@ -37,4 +37,8 @@ struct BuiltTree {
 // (child 1 is an empty leaf with an inverted box that no ray can hit).
 BuiltTree build_tree(const PrimBox* boxes, uint32_t n, const BuildParams& params);
 
+// The four-way form of a built binary tree: every inner node at an even level absorbs its two children (see Node128).
+// depth4 receives the number of four-way inner nodes on the longest root-to-leaf path (= ceil(binary depth / 2)).
+std::vector<Node128> collapse_tree4(const std::vector<Node64>& binary, uint32_t& depth4);
+
 } // namespace rt

@@ -214,7 +214,7 @@ int set_error(int code, const std::string& msg) { return fail(code, msg); }
 namespace rt {
 
 struct HostPipe {
-    static constexpr uint64_t kChunk = 1ull << 18;      // rays per chunk
+    static constexpr uint64_t kChunk = 1ull << 17;      // rays per chunk
     static constexpr size_t kInBytes = 28, kOutBytes = 20;   // per ray: origin + direction + limit in, hit record out
     struct Slot {
         char* pinIn = nullptr;
@@ -271,20 +271,34 @@ int host_pipeline(const rtgpu_scene& scene, uint64_t n, size_t outBytesPerRay, c
     const uint64_t nChunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t nThreads = (size_t)std::min<uint64_t>(nChunks, std::min<unsigned>(8u, std::max(1u, hw / 2)));
-    RT_HIP(ensure_host_pipe(scene, nThreads));
+    RT_HIP(ensure_host_pipe(scene, 2 * nThreads));   // two slots per thread: one chunk in flight while the next is filled
     std::vector<hipError_t> errs(nThreads, hipSuccess);
     auto worker = [&](size_t t) {
         hipError_t e = hipSetDevice(scene.device);
-        HostPipe::Slot& slot = scene.hostPipe->slots[t];
-        for (uint64_t c = t; c < nChunks && e == hipSuccess; c += nThreads) {
+        HostPipe::Slot* slots = &scene.hostPipe->slots[2 * t];
+        uint64_t pendingFirst[2] = {0, 0}, pendingCount[2] = {0, 0};
+        auto finish = [&](int k) {   // waits for the chunk in slot k and hands its results to the caller
+            if (pendingCount[k] == 0 || e != hipSuccess) return;
+            e = hipStreamSynchronize(slots[k].stream);
+            if (e == hipSuccess) drain(slots[k], pendingFirst[k], pendingCount[k]);
+            pendingCount[k] = 0;
+        };
+        int k = 0;
+        for (uint64_t c = t; c < nChunks && e == hipSuccess; c += nThreads, k ^= 1) {
+            finish(k);
+            if (e != hipSuccess) break;
+            HostPipe::Slot& slot = slots[k];
             const uint64_t first = c * HostPipe::kChunk, m = std::min(HostPipe::kChunk, n - first);
             const size_t inBytes = fill(slot, first, m);
             e = hipMemcpyAsync(slot.devIn, slot.pinIn, inBytes, hipMemcpyHostToDevice, slot.stream);
             if (e == hipSuccess) e = launch(slot, m);
             if (e == hipSuccess) e = hipMemcpyAsync(slot.pinOut, slot.devOut, m * outBytesPerRay, hipMemcpyDeviceToHost, slot.stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(slot.stream);
-            if (e == hipSuccess) drain(slot, first, m);
+            pendingFirst[k] = first;
+            pendingCount[k] = m;
         }
+        finish(k);
+        finish(k ^ 1);
+        if (e != hipSuccess) { (void)hipStreamSynchronize(slots[0].stream); (void)hipStreamSynchronize(slots[1].stream); }
         errs[t] = e;
     };
     std::vector<std::thread> threads;
@@ -307,7 +321,7 @@ void rtgpu_scene::release()
     rt::destroy_host_pipe(hostPipe);
     hostPipe = nullptr;
     arrays.clear();
-    const void* ptrs[] = {view.nodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
+    const void* ptrs[] = {view.nodes, view.refNodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
                           view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.envMap, view.kdPos, view.kdNormal, view.kdEnergy};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
@@ -413,8 +427,12 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     for (uint32_t i = 0; i < nInst; ++i) hasSphere = hasSphere || desc->instances[i].shape < 0;
     const bool refTop = hasSphere && nInst > 1;
     BuiltTree top;
+    std::vector<Node128> top4;
+    uint32_t topDepth4 = 0;
     RefTopTree rtop;
-    int meshDepthBudget = kStackDepth - 1;
+    // The per-lane stack holds at most 3 pending children per four-way level (+ one sentinel between the top-level tree and a
+    // mesh tree): what the top-level tree does not need is the mesh trees' budget, counted in binary levels for the builder.
+    int meshDepthBudget = std::min((int)kMaxTreeDepth, 2 * (kStackDepth / 3));
     if (refTop) {
         // sort key of InstancedModelList::sortByCentroid (:48-58): transform(shape centroid), with
         // TriangleMesh::getCentroid (shape/TriangleMesh.cpp:57-76, 205-212) for meshes
@@ -446,7 +464,6 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         if (rtop.maxDepth > (uint32_t)rt::kTopFramesHost) return fail(RTGPU_ERR_LIMIT, "top-level tree deeper than 48 levels");
         if (rtop.maxLeaf > kMaxTopLeaf) return fail(RTGPU_ERR_LIMIT, "top-level leaf with more than 256 instances");
         if (nInst >= (1u << 23)) return fail(RTGPU_ERR_LIMIT, "more than 2^23 instances in a scene with spheres");
-        meshDepthBudget = kStackDepth - 1;
     } else if (nInst > 1) {
         BuildParams tp;
         tp.maxLeaf = 1;
@@ -454,11 +471,12 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         tp.threads = threads;
         tp.maxDepth = std::min(24, ceil_log2(nInst) + 4);
         top = build_tree(instBoxes.data(), nInst, tp);
-        meshDepthBudget = kStackDepth - 1 - (int)top.maxDepth; // one entry for the mesh-tree sentinel
+        top4 = collapse_tree4(top.nodes, topDepth4);
+        meshDepthBudget = std::min((int)kMaxTreeDepth, 2 * ((kStackDepth - 1 - 3 * (int)topDepth4) / 3)); // one entry for the mesh-tree sentinel
     }
 
     // ---- mesh trees ------------------------------------------------------------------------
-    std::vector<Node64> nodes;
+    std::vector<Node128> nodes;
     std::vector<TriRec> tris;
     std::vector<uint32_t> triIds, triMat;
     std::vector<float> vertNormals;
@@ -485,7 +503,13 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         primBoxes[m].shrink_to_fit();
         meshRoot[m] = (uint32_t)nodes.size();
         meshTriBase[m] = (uint32_t)tris.size();
-        nodes.insert(nodes.end(), bt.nodes.begin(), bt.nodes.end());
+        {
+            uint32_t depth4 = 0;
+            const std::vector<Node128> four = collapse_tree4(bt.nodes, depth4);
+            bt.nodes.clear();
+            bt.nodes.shrink_to_fit();
+            nodes.insert(nodes.end(), four.begin(), four.end());
+        }
         const size_t base = tris.size();
         tris.resize(base + md.n_triangles);
         triIds.resize(base + md.n_triangles);
@@ -535,16 +559,15 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     std::vector<uint32_t> instOrder(nInst);
     for (uint32_t i = 0; i < nInst; ++i) instOrder[i] = i;
     if (refTop) {
-        nodes.insert(nodes.end(), rtop.nodes.begin(), rtop.nodes.end());
-        instOrder = rtop.order;
+        instOrder = rtop.order;   // its binary nodes go to the device as an array of their own (SceneView::refNodes)
         info.max_depth = rtop.maxDepth + info.max_depth;
     } else if (nInst > 1) {
-        nodes.insert(nodes.end(), top.nodes.begin(), top.nodes.end());
+        nodes.insert(nodes.end(), top4.begin(), top4.end());
         instOrder = top.order;
         info.n_leaves += top.leafCount;
         info.max_depth = top.maxDepth + 1 + info.max_depth;
     }
-    if (nodes.size() * sizeof(Node64) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "tree nodes exceed 4 GiB (2^26 nodes)");
+    if (nodes.size() * sizeof(Node128) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "tree nodes exceed 4 GiB (2^25 four-way nodes)");
     if (tris.size() * sizeof(TriRec) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "triangle records exceed 4 GiB (89 M triangles)");
     info.n_nodes = nodes.size();
     for (uint32_t i = 0; i < nInst; ++i) {
@@ -647,7 +670,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     uint64_t bytes = 0;
     int rc;
     using SV = SceneView;
-    if ((rc = upload(*sc, &SV::nodes, nodes, bytes)) || (rc = upload(*sc, &SV::tris, tris, bytes)) ||
+    if ((rc = upload(*sc, &SV::nodes, nodes, bytes)) || (rc = upload(*sc, &SV::refNodes, rtop.nodes, bytes)) || (rc = upload(*sc, &SV::tris, tris, bytes)) ||
         (rc = upload(*sc, &SV::triIds, triIds, bytes)) || (rc = upload(*sc, &SV::inst, inst, bytes)) || (rc = upload(*sc, &SV::instOrder, instOrder, bytes)) ||
         (rc = upload(*sc, &SV::vertNormals, vertNormals, bytes)) || (rc = upload(*sc, &SV::triMaterial, triMat, bytes)) ||
         (rc = upload(*sc, &SV::materials, mats, bytes)) || (rc = upload(*sc, &SV::pointLights, pls, bytes)) ||

@@ -165,7 +165,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
         const unsigned long long nodeMask = wave_ballot(busy && cur >= 0);
         const int nBusy = __popcll(nowBusy), nNode = __popcll(nodeMask);
         const bool nodeStep = nNode > 0 && (nBusy - nNode) * 128 < leafPct * nBusy;
-        const bool deep = wave_ballot(sp >= kStealStack) != 0ull;
+        const bool deep = wave_ballot(sp >= kStealStack - 2) != 0ull;   // a node step may push three entries
         bool done = false;
         if (nodeStep) {
             // ---- inner node ------------------------------------------------------------------------
@@ -174,28 +174,27 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 // (read before the node is asked for, so that the LDS round trip runs under the memory latency)
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
                 __builtin_amdgcn_sched_barrier(0);   // keeps the LDS read in front of the loads below
-                const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-                if (COUNT) wb += 2;
+                int c[4];
+                uint32_t tested;
+                const int nh = node4_hits(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                if (COUNT) wb += tested;
 #ifdef RT_DEV_STATS
                 dsNodeIt += 1.0f / (float)__popcll(wave_ballot(true));
 #endif
-                float t0a, t0b;
-                const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
-                const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
-                const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
-                const bool both = ha && hb, any = ha || hb;
-                const bool bFirst = hb && (!ha || t0b < t0a);      // both hit: the nearer entry first, a on ties
-                const int nearC = bFirst ? cb : ca, farC = bFirst ? ca : cb;
                 if (!deep) {
-                    L.stack[sp][lane] = farC;                       // kept only if both were hit
+                    // the nearest child is entered, the others go on the stack farthest first: c[j] at sp + nh - 1 - j
                     const int popped = L.stack[sp > 0 ? sp - 1 : 0][lane];
-                    done = !any && sp == sb;
-                    cur = any ? nearC : popped;
-                    sp += both ? 1 : ((any || done) ? 0 : -1);
+                    if (nh > 3) L.stack[sp + nh - 4][lane] = c[3];
+                    if (nh > 2) L.stack[sp + nh - 3][lane] = c[2];
+                    if (nh > 1) L.stack[sp + nh - 2][lane] = c[1];
+                    done = nh == 0 && sp == sb;
+                    cur = nh > 0 ? c[0] : popped;
+                    sp += nh > 0 ? nh - 1 : (done ? 0 : -1);
                 } else {
-                    if (both) push_deep(farC);
-                    if (any) cur = nearC;
+                    if (nh > 3) push_deep(c[3]);
+                    if (nh > 2) push_deep(c[2]);
+                    if (nh > 1) push_deep(c[1]);
+                    if (nh > 0) cur = c[0];
                     else if (sp == sb) done = true;
                     else pop_deep();
                 }
@@ -413,19 +412,15 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
         if (nodeStep) {
             // ---- inner node of the top-level tree or of a mesh tree ------------------------------------
             if (busy && cur >= 0) {
-                const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
-                const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
-                if (COUNT) wb += 2;
-                float t0a, t0b;
-                const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0a);
-                const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t0b);
-                const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
-                const bool both = ha && hb, any = ha || hb;
-                const bool bFirst = hb && (!ha || t0b < t0a);
-                const int nearC = bFirst ? cb : ca, farC = bFirst ? ca : cb;
-                if (both) push(farC);
-                if (any) cur = nearC;
+                int c[4];
+                uint32_t tested;
+                const int nh = node4_hits(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                if (COUNT) wb += tested;
+                if (nh > 3) push(c[3]);
+                if (nh > 2) push(c[2]);
+                if (nh > 1) push(c[1]);
+                if (nh > 0) cur = c[0];
                 else done = pop();
             }
         } else if (busy && cur < 0) {

@@ -158,7 +158,33 @@ __device__ __forceinline__ void xf_ray_inv(const double* m, bool identity, F3 wo
 // checks that both arrays are smaller than 4 GiB.
 __device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t node)
 {
-    return (const float4*)((const char*)sv.nodes + (node << 6));
+    return (const float4*)((const char*)sv.nodes + (node << 7));
+}
+
+// One step at an inner node of a four-way tree (Node128): the boxes of its children against the ray, and the children that
+// are hit ordered by entry distance.  c[0 .. n-1] = their references, nearest first; returns n.  `tested` = boxes tested
+// (the node's real children).  Child boxes only prune (see slab_fast), so the order is a heuristic, not part of the result.
+__device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float tlim, int c[4], uint32_t& tested)
+{
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
+    float t0, t1, t2, t3;
+    int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+    const bool h0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0);                      // the first child always exists
+    const bool h1 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t1) && c1 != kEmptyChild;
+    const bool h2 = slab_fast(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, o, inv, tlim, t2) && c2 != kEmptyChild;
+    const bool h3 = slab_fast(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
+    tested = 1u + (c1 != kEmptyChild ? 1u : 0u) + (c2 != kEmptyChild ? 1u : 0u) + (c3 != kEmptyChild ? 1u : 0u);
+    t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
+    // children that are not hit sort behind the others: a five-exchange network on (entry distance, reference)
+#define RT_CSWAP(ta, ca, tb, cb) { const bool sw = tb < ta; const float tl = sw ? tb : ta, th = sw ? ta : tb; const int cl = sw ? cb : ca, ch = sw ? ca : cb; ta = tl; tb = th; ca = cl; cb = ch; }
+    RT_CSWAP(t0, c0, t1, c1)
+    RT_CSWAP(t2, c2, t3, c3)
+    RT_CSWAP(t0, c0, t2, c2)
+    RT_CSWAP(t1, c1, t3, c3)
+    RT_CSWAP(t1, c1, t2, c2)
+#undef RT_CSWAP
+    c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
+    return (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
 }
 __device__ __forceinline__ const float4* tri_ptr(const SceneView& sv, uint32_t slot)
 {
@@ -254,26 +280,20 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
 
     bool alive = true;
     while (alive) {
-        // ---- inner nodes: one 64-byte record holds both child boxes -----------------------
+        // ---- inner nodes: one 128-byte record holds the boxes of all (up to four) children ----
         while (cur >= 0) {
-            const float4* np = node_ptr(sv, nodeBase + (uint32_t)cur);
-            const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
-            if (COUNT) nBoxes += 2;
-            float t0a, t0b;
-            const bool ha = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, best.t, t0a);
-            const bool hb = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, best.t, t0b);
-            const int ca = __float_as_int(q3.x), cb = __float_as_int(q3.y);
-            if (ha && hb) {
-                const bool aFirst = t0a <= t0b;
-                cur = aFirst ? ca : cb;
-                push(aFirst ? cb : ca);
-            } else if (ha) {
-                cur = ca;
-            } else if (hb) {
-                cur = cb;
+            int c[4];
+            uint32_t tested;
+            const int nh = node4_hits(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, best.t, c, tested);
+            if (COUNT) nBoxes += tested;
+            if (nh > 3) push(c[3]);
+            if (nh > 2) push(c[2]);
+            if (nh > 1) push(c[1]);
+            if (nh > 0) {
+                cur = c[0];
             } else {
 #ifdef RT_DEV_STATS
-                if (COUNT) nTris += 1u << 16;   // developer build: node steps that entered neither child
+                if (COUNT) nTris += 1u << 16;   // developer build: node steps that entered no child
 #endif
                 if (!pop()) {
                     alive = false;
@@ -390,7 +410,7 @@ __device__ __forceinline__ TraceResult trace_ray_reftop_closest(const SceneView&
         // ---- descend until a subtree completes ------------------------------------------------
         for (;;) {
             if (cur >= 0) {
-                const float4* np = sv.nodes + ((size_t)(sv.topRoot + (uint32_t)cur) << 2);
+                const float4* np = sv.refNodes + ((size_t)(uint32_t)cur << 2);
                 const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
                 if (COUNT) nBoxes += 2;
                 const float tsA = box_entry(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, wo, winv);
@@ -491,7 +511,7 @@ __device__ __forceinline__ bool trace_ray_reftop_any(const SceneView& sv, F3 wo,
     uint32_t nb = 0, nt = 0;
     for (;;) {
         if (cur >= 0) {
-            const float4* np = sv.nodes + ((size_t)(sv.topRoot + (uint32_t)cur) << 2);
+            const float4* np = sv.refNodes + ((size_t)(uint32_t)cur << 2);
             const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3];
             float t0a, t0b;
             const bool ha = slab_test(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, wo, winv, t0a) && t0a <= tmax;

@@ -2,12 +2,13 @@
 //
 // HBM layout of a scene (all arrays hipMalloc'ed once per scene, read-only while tracing):
 //
-//   nodes  : Node64[]  every tree (one per mesh + the top-level tree over instances)
-//            concatenated, each tree in depth-first order.  A Node64 is one INNER node and
-//            carries the boxes of BOTH children (the reference also tests both child boxes at
-//            the parent, shape/bvh/BVHNode.h:316-320), so a traversal step is one 64-byte fetch
-//            (4 x dwordx4 from one aligned 64-B block).  Leaves have no record of their own:
-//            a child reference < 0 encodes (first primitive, count).
+//   nodes  : Node128[] every tree (one per mesh + the top-level tree over instances)
+//            concatenated, each tree in depth-first order.  A Node128 is one INNER node of a four-way
+//            tree and carries the boxes of ALL its children (the reference also tests the child boxes at
+//            the parent, shape/bvh/BVHNode.h:316-320), so a traversal step is one 128-byte fetch
+//            (8 x dwordx4 from one aligned block).  Leaves have no record of their own:
+//            a child reference < 0 encodes (first primitive, count).  Node64 is the builder's binary
+//            form (and the form of the reference-order top-level tree of scenes with spheres).
 //   tris   : TriRec[]  48 bytes per triangle, in leaf order per mesh: vertex a, edges
 //            e1 = a-b, e2 = a-c (the same fp32 subtractions Triangle::intersect performs per
 //            test, math/Triangle.h:38-39) and the three cofactors of rows (e1,e2) shared by the
@@ -21,7 +22,8 @@
 
 namespace rt {
 
-constexpr int kStackDepth = 32;      // per-lane traversal stack entries: the first kLdsStack in LDS, the rest in private memory
+constexpr int kStackDepth = 96;      // per-lane traversal stack entries: the first kLdsStack in LDS, the rest in private memory
+                                     // (a four-way node leaves up to 3 pending children per level)
 constexpr int kLdsStack = 16;        // 16 x 64 lanes x 4 B = 4 KB of LDS per wave (does not limit occupancy); deeper entries are rare
 constexpr int kMaxTreeDepth = 30;    // builder guarantee per tree (top tree + mesh tree share the stack)
 constexpr int kMaxLeafHard = 16;     // leaf size field is 4 bits
@@ -42,6 +44,18 @@ struct TriRec {
     float e2x, e2y, e2z, c2;
 };
 static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
+
+// The trees the kernels walk are four-way: a Node128 is one inner node holding the boxes of its (up to four) children, made by
+// merging every inner node of the builder's binary tree with its two children (the children's children become the node's
+// children; a child that is a leaf stays one).  Half as many dependent fetches per ray as the binary form, and about a
+// third of the bookkeeping (stealing, step scheduling) per box tested.  Two 64-byte lines, eight dwordx4 loads.
+constexpr int32_t kEmptyChild = 0x7FFFFFFE;   // unused child slot of a Node128 (its box is never tested)
+struct Node128 {
+    float box[4][6];     // child k: lo.xyz, hi.xyz
+    int32_t c[4];        // >= 0: inner node index (relative to the tree's first node); < 0: leaf ~c = first << 4 | (count-1)
+    uint32_t pad[4];
+};
+static_assert(sizeof(Node128) == 128, "Node128 must be two 64-byte blocks");
 
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 4) | (count - 1)); }
 // top-level leaves (instances): up to 256 instances per leaf, first < 2^23
