@@ -100,6 +100,20 @@ def main():
         if "hbm_bytes" in e:
             e["hbm_bytes_per_launch"] = e.pop("hbm_bytes")
         summary[name] = e
+    # ---- configs[4]: trace_stage_kernel over two frames of the 49.8 M-triangle cluster
+    st5 = glob.glob(os.path.join(src, "trace_c5", "*", "*_kernel_stats.csv"))
+    if st5:
+        shutil.copy(st5[0], os.path.join(dst, tag + "_c5_kernel_stats.csv"))
+        kt5 = kernel_time(st5[0], "trace_stage_kernel")
+        c5 = {k: sum(v) / 2.0 for k, v in counters(sorted(glob.glob(os.path.join(src, "pmc_c5_*"))), "trace_stage_kernel").items()}
+        e = {"kernel": "trace_stage_kernel<kTraceSingle>", "kernel_trace": kt5}
+        if kt5:
+            e["trace_stage_ms_per_frame"] = kt5["total_ns"] / 2.0 / 1e6
+            e.update(derived(c5, kt5["total_ns"] / 2.0 / 1e9))
+            if "hbm_bytes" in e:
+                e["hbm_bytes_per_frame"] = e.pop("hbm_bytes")
+        summary["c5_trace_stage"] = e
+        summary["commands"]["configs[4]"] = "RTGPU_RENDER_LANES=1 rocprofv3 [...] -- python3 scripts/prof_c5.py (two frames; figures per frame)"
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

@@ -31,6 +31,18 @@ e1.record(stream); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 10
 hf = hits.cpu().numpy().view(np.uint32)
 print(f"flattened primary: {ms:.3f} ms {n/ms/1e3:.0f} Mrays/s hit fraction {(hf[:,2]!=0xFFFFFFFF).mean():.3f}", flush=True)
+# the path-traced frame of configs[4]: 1080p, 4x4 spp, path length 9
+fst = abi.make_settings(W, H, geometry_aa=4, material_aa=4, max_path_length=9, seed=1)
+fb = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+r = api.Renderer()
+r.render_device(g, cam, fst, fb)
+s = r.render_device(g, cam, fst, fb)
+if hasattr(r, "render_profile_device"):
+    p = r.render_profile_device(g, cam, fst, fb)
+    print(f"frame 4x4: {s.device_ms:.1f} ms, {(s.primary_rays + s.extension_rays + s.shadow_rays) / s.device_ms / 1e3:.0f} Mrays/s; trace stage {p.trace_ms:.1f} ms = {(s.extension_rays + s.shadow_rays) / p.trace_ms / 1e3:.0f} Mrays/s", flush=True)
+else:
+    print(f"frame 4x4: {s.device_ms:.1f} ms, {(s.primary_rays + s.extension_rays + s.shadow_rays) / s.device_ms / 1e3:.0f} Mrays/s", flush=True)
+del fb
 g.close()
 sc2, _, _ = scenes.cluster_scene(args.copies, args.subdiv, flatten=False)
 g2 = api.Scene(sc2)

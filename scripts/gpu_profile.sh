@@ -13,6 +13,11 @@ cd "$(dirname "$0")/.." || exit 1
 HEAD="python3 bench.py --no-cpu-baseline --no-extras --no-roofline"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace" -- $HEAD --steps 3 --warmup 1 > "$out/bench_trace.log" 2>&1 || exit 1
 timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c2" -- python3 scripts/prof_c2.py > "$out/c2_trace.log" 2>&1 || exit 1
+timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d "$out/trace_c5" -- python3 scripts/prof_c5.py > "$out/c5_trace.log" 2>&1 || exit 1
+for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum"; do
+    name=$(echo "$group" | cut -d' ' -f1)
+    timeout -s KILL 240 rocprofv3 --pmc $group --output-format csv -d "$out/pmc_c5_$name" -- python3 scripts/prof_c5.py > "$out/c5_$name.log" 2>&1 || exit 1
+done
 for group in "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY"; do
     name=$(echo "$group" | cut -d' ' -f1)
     timeout -s KILL 240 rocprofv3 --pmc $group --output-format csv -d "$out/pmc_head_$name" -- $HEAD --steps 1 --warmup 0 > "$out/bench_$name.log" 2>&1 || exit 1
