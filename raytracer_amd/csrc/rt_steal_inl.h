@@ -58,6 +58,11 @@ __device__ __forceinline__ unsigned long long pack_hit(float t, uint32_t id)
 }
 
 __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+// set bits of `m` below this lane's position
+__device__ __forceinline__ int lanes_below(unsigned long long m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 // beta / gamma of the hit trace_wave_steal() reported for world-space ray (wo, wd).
 __device__ __forceinline__ void hit_barycentrics(const SceneView& sv, uint32_t slot, F3 wo, F3 wd, float& beta, float& gamma)
@@ -199,37 +204,70 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                     else pop_deep();
                 }
             }
-        } else if (busy && cur < 0) {
-            // ---- one triangle of a leaf ------------------------------------------------------------
+        } else {
+            // ---- leaf step: the triangles waiting at the wave's leaves, dealt out over all 64 lanes -----------
+            // A lane at a leaf offers up to four of its triangles; offers are numbered across the wave (prefix
+            // counts from three ballots) and written to a list, and lane k tests offer k with the offering
+            // lane's ray.  Results meet in best[], so who tests what does not matter.
+            const bool atLeaf = busy && cur < 0;
             const uint32_t leaf = (uint32_t)(~cur);
-            const uint32_t slot = triBase + (leaf >> 4);
-            const float4* tp = tri_ptr(sv, slot);
-            const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-            float t, be, ga;
-            if (COUNT) wt += 1;
+            const int left = (int)(leaf & 15u) + 1;
+            const int want = atLeaf ? (left < 4 ? left : 4) : 0;
+            const unsigned long long m0 = wave_ballot(atLeaf);
+            const unsigned long long m1 = wave_ballot(atLeaf && ((want - 1) & 1) != 0);
+            const unsigned long long m2 = wave_ballot(atLeaf && ((want - 1) & 2) != 0);
+            const int pre = lanes_below(m0) + lanes_below(m1) + 2 * lanes_below(m2);
+            const int total = __popcll(m0) + __popcll(m1) + 2 * __popcll(m2);
+            int served = 64 - pre;
+            served = served < want ? served : want;
+            served = served > 0 ? served : 0;
+            if (served > 0) L.giveList[pre] = lane;
+            if (served > 1) L.giveList[pre + 1] = lane | (1 << 6);
+            if (served > 2) L.giveList[pre + 2] = lane | (2 << 6);
+            if (served > 3) L.giveList[pre + 3] = lane | (3 << 6);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            const bool helper = lane < total;
+            const int e = L.giveList[helper ? lane : 0];
+            const int src = e & 63;
+            const int hcur = __shfl(cur, src, 64);
+            const int howner = __shfl(owner, src, 64);
+            const float hox = __shfl(o.x, src, 64), hoy = __shfl(o.y, src, 64), hoz = __shfl(o.z, src, 64);
+            const float hdx = __shfl(d.x, src, 64), hdy = __shfl(d.y, src, 64), hdz = __shfl(d.z, src, 64);
+            const float hlim = __shfl(ANY ? rtmax : tlim, src, 64);
+            if (helper) {
+                const uint32_t slot = triBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
+                const float4* tp = tri_ptr(sv, slot);
+                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                float t, be, ga;
 #ifdef RT_DEV_STATS
-            dsLeafIt += 1.0f / (float)__popcll(wave_ballot(true));
+                dsLeafIt += 1.0f / (float)__popcll(wave_ballot(true));
 #endif
-            if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
-                if (ANY) {
-                    if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
-                } else if (t <= tlim) {
-                    const unsigned long long mine = pack_hit(t + 0.0f, sv.triIds[slot]);   // -0 (a ray that starts in the triangle's plane) as +0
-                    const unsigned long long old = atomicMin(&L.best[owner], mine);
-                    if (mine < old && L.best[owner] == mine) L.paySlot[owner] = slot;
+                if (tri_test(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, be, ga) && t <= hlim) {
+                    if (ANY) {
+                        atomicMin(&L.best[howner], 0ull);
+                    } else {
+                        const unsigned long long mine = pack_hit(t + 0.0f, sv.triIds[slot]);   // -0 (a ray that starts in the triangle's plane) as +0
+                        const unsigned long long old = atomicMin(&L.best[howner], mine);
+                        if (mine < old && L.best[howner] == mine) L.paySlot[howner] = slot;
+                    }
                 }
             }
-            const unsigned long long b = L.best[owner];
-            tlim = __uint_as_float((uint32_t)(b >> 32));
-            if ((leaf & 15u) != 0u && !(ANY && b == 0ull)) {
-                cur = ~(int)(leaf + 15u);                           // first + 1, count - 1
-            } else if ((ANY && b == 0ull) || sp == sb) {
-                done = true;
-            } else if (!deep) {
-                --sp;
-                cur = L.stack[sp][lane];
-            } else {
-                pop_deep();
+            __builtin_amdgcn_wave_barrier();
+            if (served > 0) {
+                if (COUNT) wt += (uint32_t)served;
+                const unsigned long long b = L.best[owner];
+                tlim = __uint_as_float((uint32_t)(b >> 32));
+                if (left > served && !(ANY && b == 0ull)) {
+                    cur = ~(int)(leaf + 15u * (uint32_t)served);        // first + served, count - served
+                } else if ((ANY && b == 0ull) || sp == sb) {
+                    done = true;
+                } else if (!deep) {
+                    --sp;
+                    cur = L.stack[sp][lane];
+                } else {
+                    pop_deep();
+                }
             }
         }
         if (done) {
@@ -423,9 +461,64 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 if (nh > 0) cur = c[0];
                 else done = pop();
             }
-        } else if (busy && cur < 0) {
+        } else {
+            // ---- leaf step: mesh triangles dealt out over all 64 lanes (see trace_wave_steal), then top-level leaves
+            const bool atLeaf = busy && cur < 0;
+            const bool triLeaf = atLeaf && inMesh;
             const uint32_t leaf = (uint32_t)(~cur);
-            if (!inMesh) {
+            const int left = (int)(leaf & 15u) + 1;
+            const int want = triLeaf ? (left < 4 ? left : 4) : 0;
+            const unsigned long long m0 = wave_ballot(triLeaf);
+            if (m0 != 0ull) {
+                const unsigned long long m1 = wave_ballot(triLeaf && ((want - 1) & 1) != 0);
+                const unsigned long long m2 = wave_ballot(triLeaf && ((want - 1) & 2) != 0);
+                const int pre = lanes_below(m0) + lanes_below(m1) + 2 * lanes_below(m2);
+                const int total = __popcll(m0) + __popcll(m1) + 2 * __popcll(m2);
+                int served = 64 - pre;
+                served = served < want ? served : want;
+                served = served > 0 ? served : 0;
+                if (served > 0) L.giveList[pre] = lane;
+                if (served > 1) L.giveList[pre + 1] = lane | (1 << 6);
+                if (served > 2) L.giveList[pre + 2] = lane | (2 << 6);
+                if (served > 3) L.giveList[pre + 3] = lane | (3 << 6);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                const bool helper = lane < total;
+                const int e = L.giveList[helper ? lane : 0];
+                const int src = e & 63;
+                const int hcur = __shfl(cur, src, 64);
+                const int howner = __shfl(owner, src, 64);
+                const uint32_t htriBase = (uint32_t)__shfl((int)triBase, src, 64), hkeyBase = (uint32_t)__shfl((int)keyBase, src, 64);
+                const uint32_t hinst = (uint32_t)__shfl((int)curInst, src, 64);
+                const float hox = __shfl(o.x, src, 64), hoy = __shfl(o.y, src, 64), hoz = __shfl(o.z, src, 64);
+                const float hdx = __shfl(d.x, src, 64), hdy = __shfl(d.y, src, 64), hdz = __shfl(d.z, src, 64);
+                const float hlim = __shfl(ANY ? rtmax : tlim, src, 64);
+                if (helper) {
+                    const uint32_t slot = htriBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
+                    const float4* tp = tri_ptr(sv, slot);
+                    const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
+                    float t, be, ga;
+                    if (tri_test(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, be, ga) && t <= hlim) {
+                        if (ANY) {
+                            atomicMin(&L.best[howner], 0ull);
+                        } else {
+                            const unsigned long long mine = pack_hit(t + 0.0f, hkeyBase + sv.triIds[slot]);   // -0 as +0, see pack_hit
+                            const unsigned long long old = atomicMin(&L.best[howner], mine);
+                            if (mine < old && L.best[howner] == mine) { L.paySlot[howner] = slot; L.payInst[howner] = hinst; }
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (served > 0) {
+                    if (COUNT) wt += (uint32_t)served;
+                    const unsigned long long b = L.best[owner];
+                    tlim = __uint_as_float((uint32_t)(b >> 32));
+                    if (ANY && b == 0ull) done = true;
+                    else if (left > served) cur = ~(int)(leaf + 15u * (uint32_t)served);
+                    else done = pop();
+                }
+            }
+            if (atLeaf && !triLeaf) {
                 // ---- top-level leaf: enter the instance (InstancedModelList::traceRay, shape/list/InstancedModelList.cpp:99-138)
                 curInst = sv.instOrder[leaf >> 4];
                 const DevInstance& in = sv.inst[curInst];
@@ -439,27 +532,6 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 if (sp > sb) { sentPos = sp; push(kSentinel); }
                 else sentPos = -1;
                 cur = 0;
-            } else {
-                // ---- one triangle of a mesh leaf -------------------------------------------------------
-                const uint32_t slot = triBase + (leaf >> 4);
-                const float4* tp = tri_ptr(sv, slot);
-                const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                float t, be, ga;
-                if (COUNT) wt += 1;
-                if (tri_test(r0, r1, r2, o, d, t, be, ga)) {
-                    if (ANY) {
-                        if (t <= rtmax) { atomicMin(&L.best[owner], 0ull); }
-                    } else if (t <= tlim) {
-                        const unsigned long long mine = pack_hit(t + 0.0f, keyBase + sv.triIds[slot]);   // -0 as +0, see pack_hit
-                        const unsigned long long old = atomicMin(&L.best[owner], mine);
-                        if (mine < old && L.best[owner] == mine) { L.paySlot[owner] = slot; L.payInst[owner] = curInst; }
-                    }
-                }
-                const unsigned long long b = L.best[owner];
-                tlim = __uint_as_float((uint32_t)(b >> 32));
-                if (ANY && b == 0ull) done = true;
-                else if ((leaf & 15u) != 0u) cur = ~(int)(leaf + 15u);
-                else done = pop();
             }
         }
         if (done) {
