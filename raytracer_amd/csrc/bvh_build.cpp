@@ -359,9 +359,9 @@ struct Collapser {
         for (int k = 0; k < 4; ++k) {
             Node128& d = out[(size_t)idx];
             if (k < nk) {
-                for (int a = 0; a < 3; ++a) { d.box[k][a] = kids[k].lo[a]; d.box[k][3 + a] = kids[k].hi[a]; }
+                for (int a = 0; a < 3; ++a) { d.box[k][2 * a] = kids[k].lo[a]; d.box[k][2 * a + 1] = kids[k].hi[a]; }
             } else {
-                for (int a = 0; a < 3; ++a) { d.box[k][a] = FLT_MAX; d.box[k][3 + a] = -FLT_MAX; }
+                for (int a = 0; a < 3; ++a) { d.box[k][2 * a] = FLT_MAX; d.box[k][2 * a + 1] = -FLT_MAX; }
                 d.c[k] = kEmptyChild;
             }
             d.pad[k] = 0;

@@ -77,6 +77,21 @@ __device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float
     return tnear <= tfar;
 }
 
+// slab_fast on a box stored as (lo, hi) pairs per axis: the two planes of an axis go through one packed
+// subtract and one packed multiply (v_pk_add_f32 / v_pk_mul_f32, each an IEEE operation per half, so the
+// result equals slab_fast's).
+typedef float Pair __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ bool slab_pairs(float lox, float hix, float loy, float hiy, float loz, float hiz,
+                                           F3 o, F3 inv, float tlimit, float& t0)
+{
+    const Pair px = {lox, hix}, py = {loy, hiy}, pz = {loz, hiz};
+    const Pair tx = (px - o.x) * inv.x, ty = (py - o.y) * inv.y, tz = (pz - o.z) * inv.z;
+    const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
+    const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
+    t0 = tnear;
+    return tnear <= tfar;
+}
+
 // Triangle::intersect (math/Triangle.h:34-101) on a TriRec.  c0..c2 are the cofactors
 // (e1.y*e2.z-e1.z*e2.y), (e1.x*e2.z-e1.z*e2.x), (e1.x*e2.y-e1.y*e2.x) that both the pDet and
 // the p0Det expansion use; precomputing them performs the same fp32 operations once.
@@ -169,10 +184,10 @@ __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float 
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
     float t0, t1, t2, t3;
     int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
-    const bool h0 = slab_fast(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0);                      // the first child always exists
-    const bool h1 = slab_fast(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t1) && c1 != kEmptyChild;
-    const bool h2 = slab_fast(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, o, inv, tlim, t2) && c2 != kEmptyChild;
-    const bool h3 = slab_fast(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
+    const bool h0 = slab_pairs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0);                      // the first child always exists
+    const bool h1 = slab_pairs(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t1) && c1 != kEmptyChild;
+    const bool h2 = slab_pairs(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, o, inv, tlim, t2) && c2 != kEmptyChild;
+    const bool h3 = slab_pairs(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
     tested = 1u + (c1 != kEmptyChild ? 1u : 0u) + (c2 != kEmptyChild ? 1u : 0u) + (c3 != kEmptyChild ? 1u : 0u);
     t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
     // children that are not hit sort behind the others: a five-exchange network on (entry distance, reference)

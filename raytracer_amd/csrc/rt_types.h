@@ -51,7 +51,7 @@ static_assert(sizeof(TriRec) == 48, "TriRec must be 48 bytes");
 // third of the bookkeeping (stealing, step scheduling) per box tested.  Two 64-byte lines, eight dwordx4 loads.
 constexpr int32_t kEmptyChild = 0x7FFFFFFE;   // unused child slot of a Node128 (its box is never tested)
 struct Node128 {
-    float box[4][6];     // child k: lo.xyz, hi.xyz
+    float box[4][6];     // child k: lo.x, hi.x, lo.y, hi.y, lo.z, hi.z (plane pairs side by side for the packed fp32 instructions)
     int32_t c[4];        // >= 0: inner node index (relative to the tree's first node); < 0: leaf ~c = first << 4 | (count-1)
     uint32_t pad[4];
 };

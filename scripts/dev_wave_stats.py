@@ -27,9 +27,9 @@ def stats(g, o, d, label, show_timeline=False):
     boxes = w[:, :, 0].sum()
     tris = w[:, 8:, 1].sum() * 64 / 56
     outer, steal, nodeit, leafit, busy, stolen = w[:, :6, 1].sum(0).astype(np.float64)
-    print(f"{label}: rays={n} waves={nw} lane node visits/ray={boxes/2/n:.2f} tris/ray~{tris/n:.2f}")
+    print(f"{label}: rays={n} waves={nw} boxes/ray={boxes/n:.2f} tris/ray~{tris/n:.2f}")
     print(f"   per wave: iterations={outer/nw:.1f} steal rounds={steal/nw:.1f} stolen entries={stolen/nw:.1f} node steps={nodeit/nw:.1f} leaf steps={leafit/nw:.1f} busy lanes per iteration={busy/max(outer,1):.1f}")
-    print(f"   node-step SIMT efficiency={boxes/2/(nodeit*64):.3f} leaf-step SIMT efficiency~{tris/(leafit*64):.3f}")
+    print(f"   boxes per node step={boxes/nodeit:.1f} (of 256) triangles per leaf step~{tris/leafit:.1f} (of 64)")
     t0 = w[:, 6, 1]; t1 = w[:, 7, 1]
     base = t0.min()
     t0 = (t0 - base) / 100.0; t1 = (t1 - base) / 100.0   # us (100 MHz clock)
