@@ -41,18 +41,29 @@ def ray_bytes(rays, boxes, tris, out_bytes):
 
 
 def roofline(alg_bytes, kernel_ms, scene_bytes, kernel, extra=None):
-    """bound = the memory level the scene's size puts the traversal in: HBM when the scene is larger than the Infinity
-    Cache, else L2 (a tree walk re-reads the upper levels, which the caches serve: "achieved" is the algorithmic rate
-    against the bandwidth of that level)."""
+    """The traversal kernels' algorithmic bytes -- every child box and triangle a ray tests -- are what the L2 level has
+    to deliver to the compute units (the 32 KB L1 of a CU holds next to nothing of a tree): "achieved" is that rate
+    against the aggregate L2 bandwidth.  How much of it HBM had to deliver is a different, smaller number (the upper tree
+    levels are re-read from L2 and the Infinity Cache): `traffic` / `hbm` carry it when committed counters of the same
+    frame exist, `frac_of_hbm_peak` is the algorithmic rate against the HBM peak (above 1 for cache-resident scenes)."""
     achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    hbm = scene_bytes > MALL_BYTES and achieved < HBM_PEAK_GBS
-    peak = HBM_PEAK_GBS if hbm else L2_PEAK_GBS
-    out = {"bound": "hbm" if hbm else "l2", "achieved": achieved, "peak": peak, "unit": "GB/s", "frac": achieved / peak,
+    out = {"bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
            "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
-           "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "scene_bytes": scene_bytes}
+           "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "scene_bytes": scene_bytes,
+           "scene_fits_infinity_cache": bool(scene_bytes <= MALL_BYTES)}
     if extra:
         out.update(extra)
     return out
+
+
+def attach_counters(rl, c, src, per):
+    """Quotes committed PMC figures (same kernel, same workload) beside a live roofline."""
+    rl["traffic"] = c.get("hbm_bytes_per_" + per)
+    rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
+    if c.get("hbm_GBps"):
+        rl["hbm"] = {"GBps": c["hbm_GBps"], "frac_of_peak": c["hbm_GBps"] / HBM_PEAK_GBS, "l2_hit_rate": c.get("l2_hit_rate"),
+                     "note": "2 x FETCH_SIZE + WRITE_SIZE over the kernel's time; an upper bound for 16-byte gathers",
+                     "source": "committed profile " + src + " (not measured in this run)"}
 
 
 def committed_counters(tag):
@@ -244,11 +255,11 @@ def bench_c2(args, torch, api, abi, scenes, dev):
     ms, boxes, tris, hits = timed(d_o, d_d)
     counters, src = committed_counters(args.profile_tag)
     extra = {"kernel_ms_avg_per_launch": ms, "boxes_per_ray": boxes / n, "tris_per_ray": tris / n, "measured": "HIP events around each launch in this run"}
-    if counters and "c2_primary" in counters:
-        extra["counters"] = dict(counters["c2_primary"], source="committed profile " + src + " (not measured in this run)")
     out["primary"] = {"workload": "configs[1]: %d triangles, %dx%d primary rays, closest hit" % (sc.n_triangles(), W, H),
                       "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
                       "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
+    if counters and "c2_primary" in counters:
+        attach_counters(out["primary"]["roofline"], counters["c2_primary"], src, "launch")
     # bounce rays: from every primary hit point, a direction in the hemisphere of the (radial) outward normal
     h = hits.cpu().numpy().view(np.uint32)
     hit = h[:, 2] != 0xFFFFFFFF
@@ -266,11 +277,11 @@ def bench_c2(args, torch, api, abi, scenes, dev):
     b_o, b_d = torch.from_numpy(so).to(dev), torch.from_numpy(sd.astype(np.float32)).to(dev)
     ms, boxes, tris, _ = timed(b_o, b_d)
     extra = {"kernel_ms_avg_per_launch": ms, "boxes_per_ray": boxes / n, "tris_per_ray": tris / n, "measured": "HIP events around each launch in this run"}
-    if counters and "c2_bounce" in counters:
-        extra["counters"] = dict(counters["c2_bounce"], source="committed profile " + src + " (not measured in this run)")
     out["bounce"] = {"workload": "configs[1] scene, %d diffuse-bounce rays from the primary hit points in pixel order (incoherent)" % n,
                      "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
                      "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
+    if counters and "c2_bounce" in counters:
+        attach_counters(out["bounce"]["roofline"], counters["c2_bounce"], src, "launch")
     # the host-pointer entry point (rays and hits cross PCIe inside the call)
     o_h, d_h = d_o.cpu().numpy(), d_d.cpu().numpy()
     scene.trace_rays(o_h, d_h)
@@ -410,9 +421,7 @@ def main():
             rl, stages = frame_rooflines(torch, api, abi, res["handle"], res["cam"], st, dev, info, "trace_stage_kernel<kTraceSingle>")
             counters, src = committed_counters(args.profile_tag)
             if counters and "headline_trace_stage" in counters:
-                c = counters["headline_trace_stage"]
-                rl["traffic"] = c.get("hbm_bytes_per_frame")
-                rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
+                attach_counters(rl, counters["headline_trace_stage"], src, "frame")
             out["roofline"] = rl
             out["stages_one_batch_in_flight"] = stages
         if not args.no_cpu_baseline:
@@ -441,9 +450,7 @@ def main():
         c5 = extras.get("configs[4]", {})
         if counters and "c5_trace_stage" in counters and "roofline" in c5 and args.subdiv == 8:
             # the committed counters are of this very frame: the fabric traffic they show is what HBM actually had to deliver
-            c = counters["c5_trace_stage"]
-            c5["roofline"]["traffic"] = c.get("hbm_bytes_per_frame")
-            c5["roofline"]["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
+            attach_counters(c5["roofline"], counters["c5_trace_stage"], src, "frame")
         out["extras"] = extras
     if rank == 0:
         print(json.dumps(out))
