@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -268,6 +269,7 @@ template <typename Fill, typename Launch, typename Drain>
 int host_pipeline(const rtgpu_scene& scene, uint64_t n, size_t outBytesPerRay, const Fill& fill, const Launch& launch, const Drain& drain)
 {
     using rt::HostPipe;
+    std::lock_guard<std::mutex> cacheLock(scene.cacheMutex);
     const uint64_t nChunks = (n + HostPipe::kChunk - 1) / HostPipe::kChunk;
     const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
     const size_t nThreads = (size_t)std::min<uint64_t>(nChunks, std::min<unsigned>(8u, std::max(1u, hw / 2)));

@@ -1299,6 +1299,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
                             float* dOut, rtgpu_render_stats* stats, uint64_t* work, hipStream_t stream, std::string& err, rtgpu_render_profile* profile)
 {
     const SceneView& sv = scene.view;
+    std::lock_guard<std::mutex> cacheLock(scene.cacheMutex);
     Batch proto;
     const uint64_t nPixelsTotal = call_pixels(st, order, proto);
     if (stats) *stats = rtgpu_render_stats{};

@@ -5,6 +5,7 @@
 #include <new>
 #include <stdexcept>
 #include <string>
+#include <mutex>
 #include <vector>
 
 #include "../../include/rtgpu.h"
@@ -36,6 +37,9 @@ struct rtgpu_scene {
     rtgpu_scene_info info{};
     std::vector<rtgpu_photon> photons;   // the photon map's photons in emission order (host copy)
     std::vector<rt::SceneArray> arrays;  // every device array `view` points to
+    // Serialises the calls that use the state cached below (renders, host-pointer ray batches): two host threads may call into
+    // one scene at once, the second waits.  Device-pointer ray batches keep nothing and do not take it.
+    mutable std::mutex cacheMutex;
     mutable rt::RenderCache* renderCache = nullptr;
     mutable rt::HostPipe* hostPipe = nullptr;
     mutable rtgpu_multi* multi = nullptr;
