@@ -453,6 +453,41 @@ def test_scene_copy_on_the_same_device_renders_identically():
             assert h.info().n_triangles == g.info().n_triangles and len(h.photons()) == len(g.photons())
 
 
+def test_two_host_threads_on_one_scene_take_turns():
+    """Renders and host-array ray batches keep their workspace with the scene; calls from several host threads must
+    neither corrupt it nor each other's results."""
+    import threading
+    sc, cam_m, yfov = scenes.box_scene(with_mirror=True)
+    W, H = 48, 36
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    sts = [abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=s) for s in (1, 2)]
+    o, d = oracle.generate_primary(cam, abi.make_settings(W, H, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER))
+    with api.Scene(sc) as g:
+        want = [api.Renderer().render(g, cam, st)[0] for st in sts]
+        want_hits = g.trace_rays(o, d)
+        got, errors = {}, []
+
+        def work(k):
+            try:
+                for rep in range(3):
+                    got[(k, rep)] = api.Renderer().render(g, cam, sts[k])[0]
+                    got[("hits", k, rep)] = g.trace_rays(o, d)
+            except Exception as e:  # noqa: BLE001
+                errors.append(e)
+
+        threads = [threading.Thread(target=work, args=(k,)) for k in (0, 1)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+        assert not errors, errors
+        for k in (0, 1):
+            for rep in range(3):
+                assert np.array_equal(got[(k, rep)], want[k])
+                for f in ("t", "prim", "inst"):
+                    assert np.array_equal(got[("hits", k, rep)][f], want_hits[f])
+
+
 def test_render_work_counts_and_same_image():
     """rtgpu_render_work_device: the counting render gives the image of the ordinary one and ray counts that match its
     statistics; boxes and triangles per ray are in the range the tree allows."""
