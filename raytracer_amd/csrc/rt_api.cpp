@@ -601,6 +601,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         dm.first = m.first;
         dm.second = m.second;
         dm.intensity = m.intensity;
+        dm.intensityOverPi = m.intensity / 3.14159265358979323;   // math/Constants.h
         dm.texture = m.texture;
         dm.variance = material_variance(*desc, i, 0);
         dm.normalMap = m.normal_map;
@@ -702,6 +703,17 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     v.nPointLights = desc->n_point_lights;
     v.nAreaLights = desc->n_area_lights;
     v.nDirLights = desc->n_directional_lights;
+    {
+        // the pick probabilities of NextEventEstimation::sample, formed once with the operations of the per-sample code
+        const bool hasPoint = v.nPointLights > 0, hasArea = v.nAreaLights > 0, hasDir = v.nDirLights > 0;
+        const float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f) + (hasDir ? 1.0f : 0.0f);
+        v.neePointP = (hasPoint ? 1.0f : 0.0f) / total;
+        v.neeAreaP = (hasArea ? 1.0f : 0.0f) / total;
+        v.neeDirP = (hasDir ? 1.0f : 0.0f) / total;
+        v.neePointScale = 1.0f / (v.neePointP * (1.0f / (float)v.nPointLights));
+        v.neeAreaScale = 1.0f / (v.neeAreaP * (1.0f / (float)v.nAreaLights));
+        v.neeDirScale = 1.0f / (v.neeDirP * (1.0f / (float)v.nDirLights));
+    }
     v.hasEnv = desc->has_environment;
     v.envW = desc->env_map_width;
     v.envH = desc->env_map_height;

@@ -19,6 +19,7 @@ struct DevMaterial {
     uint32_t variance;  // IMaterial::hasVariance: 0 no, 1 yes, 2 depends on the hit (a Fresnel mix below decides)
     uint32_t normalMap; // 1 + texture index of a diffuse / glossy normal map, 0 = none
     uint32_t varianceMap; // `variance` for a vertex where diffuse closures read the photon map (they have no variance there)
+    double intensityOverPi; // intensity / PI, the factor of DiffuseMaterial::bsdf (material/DiffuseMaterial.cpp:183-195), computed once
 };
 
 struct DevTexture {
@@ -40,6 +41,9 @@ struct DevAreaLight {
     double intensity;
     float normal[3]; // AreaLight::getNormal, light/AreaLight.cpp:43-48
     float area;      // Triangle::getSurfaceArea, math/Triangle.h:7-18
+    // the same for every sample of the light, so computed once on the host with the operations the per-sample code would use:
+    float irradiance[3];   // color.scale(intensity).divide(area): the "lightIrradiance" of Renderer.cpp:199-200, GlossyMaterial.cpp:200-201
+    float radiance[3];     // irradiance.divide(PI), NextEventEstimation.cpp (neeAreaLight)
 };
 
 struct DevDirectionalLight {
@@ -80,6 +84,9 @@ struct SceneView {
     const uint32_t* texels;     // RGBA8 texels of all textures
     const double* instFwd;      // per instance: rows 0..2 of the object->world matrix; null unless a normal map is used
     uint32_t nMaterials, nPointLights, nAreaLights, nDirLights;
+    // NextEventEstimation::sample's pick probabilities (material/NextEventEstimation.cpp:8-120), the same for every sample:
+    // P(light kind), and 1 / (P(kind) * P(light of that kind)) as rgb_div_f would form it
+    float neePointP, neeAreaP, neeDirP, neePointScale, neeAreaScale, neeDirScale;
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
     int32_t hasGlass;           // some material is glass: paths carry the extra records of a glass vertex

@@ -123,6 +123,7 @@ struct Batch {
     // a rank walks its squares in order and each square row by row; results go to a compact buffer in that order
     // (squares that stick out of the tile keep their full T x T slots, the outside pixels are written as zeros).
     uint32_t tileSize, nRanks, rank, tilesX, nTiles;
+    uint32_t sqrtM;       // (int)sqrt((double)material_aa): the stratification grid of a sample's first variance vertex
 };
 
 // Position `idx` of the call's pixel order -> pixel (x, y).  Returns the pixel's index in the frame buffer (the key
@@ -391,7 +392,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 done = true;
                 completed = k + 1 != maxLen;
                 const DevAreaLight& L = sv.areaLights[lightIdx];
-                const RGBf lightRadiance = rgb_div_d(area_light_irradiance(L), RT_PI);
+                const RGBf lightRadiance = rgb(L.radiance[0], L.radiance[1], L.radiance[2]);
                 const F3 lampPoint = d * metaT;   // as the reference has it: not offset by the hit point
                 const F3 objectToLamp = normalized3(lampPoint - hp);
                 const float angle = fmaxf(0.0f, dot3(f3(gn.x, gn.y, gn.z), objectToLamp));
@@ -456,6 +457,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             const bool isFirstVar = curVar && !passed;
             const int sampleCount = isFirstVar ? (int)M : 1;
             const int sampleI = isFirstVar ? (int)j : 0;
+            const int sampleGrid = isFirstVar ? (int)batch.sqrtM : 1;   // (int)sqrt((double)sampleCount)
             passed = passed || curVar;
             if (passed) state |= ST_PASSED_VAR;
             if (curVar && j == 0) pool.sHasVar[s] = 1;
@@ -654,14 +656,14 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;
                     if (useNEE) {
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, pixel, rs, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);   // what the vertex is worth when the light is hidden
                         if (ns.valid) {
                             const double angle = fmaxf(0.0f, dot3(normal, ns.dir));
                             const RGBf direct = rgb_scale_d(ns.radiance, angle);
-                            const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensity / RT_PI), 2.0f);
+                            const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensityOverPi), 2.0f);
                             const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, rgb_mul(color, value))));
                             o = hitpoint + (ns.dir * 0.0001f);
                             d = ns.dir;
@@ -673,7 +675,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     } else {
                         const Basis3 basis = basis_from(normal);
                         float sx, sy;
-                        stratified_square((int)sqrt((double)sampleCount), (float)sampleI,
+                        stratified_square(sampleGrid, (float)sampleI,
                                           rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_X), rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_Y), sx, sy);
                         const F3 l = cosine_hemisphere(sx, sy);
                         const F3 dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
@@ -710,7 +712,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     const bool neeEnabled = roughness > 0;
                     const bool useNEE = neeEnabled && rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5;
                     if (useNEE) {
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleCount, st.seed, pixel, rs, vk);
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, pixel, rs, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);
@@ -1213,6 +1215,13 @@ void area_light_derived(DevAreaLight& l)
     float h[3] = {ac[0] - v1n[0] * pr, ac[1] - v1n[1] * pr, ac[2] - v1n[2] * pr};
     const float height = std::sqrt(dot(h, h));
     l.area = v1Length * height / 2.0f;
+    // RGB::scale(double) / RGB::divide(double) (film/RGB.h:44-47, 60-63): promote, multiply, narrow, per channel
+    const double pi = 3.14159265358979323;   // math/Constants.h
+    for (int k = 0; k < 3; ++k) {
+        const float e = (float)(l.color[k] * l.intensity);
+        l.irradiance[k] = (float)(e * (1.0 / (double)l.area));
+        l.radiance[k] = (float)(l.irradiance[k] * (1.0 / pi));
+    }
 }
 
 // ---- host side ---------------------------------------------------------------------------------------
@@ -1258,6 +1267,7 @@ uint64_t call_pixels(const rtgpu_render_settings& st, const TileOrder* order, Ba
 {
     const uint32_t tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
     proto = Batch{};
+    proto.sqrtM = (uint32_t)(int)std::sqrt((double)st.material_aa);
     if (!order || order->tileSize == 0) return (uint64_t)tw * th;
     const uint32_t T = order->tileSize;
     proto.tileSize = T;

@@ -147,12 +147,9 @@ __device__ __forceinline__ bool area_light_hit(const DevAreaLight& L, F3 o, F3 d
     return tri_test(r0, r1, r2, o, d, t, be, ga);
 }
 
-// light.color * light.intensity / area (the "lightIrradiance" of Renderer.cpp:199-200, GlossyMaterial.cpp:200-201)
-__device__ __forceinline__ RGBf area_light_irradiance(const DevAreaLight& L)
-{
-    const RGBf e = rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity);
-    return rgb_div_d(e, (double)L.area);
-}
+// light.color * light.intensity / area (the "lightIrradiance" of Renderer.cpp:199-200, GlossyMaterial.cpp:200-201);
+// scene creation computed it with area_light_constants() below
+__device__ __forceinline__ RGBf area_light_irradiance(const DevAreaLight& L) { return rgb(L.irradiance[0], L.irradiance[1], L.irradiance[2]); }
 
 struct NeeSample {
     RGBf radiance;   // value of NextEventEstimation::sample if the shadow ray is unoccluded
@@ -179,7 +176,8 @@ __device__ __forceinline__ F3 sample_steradian_sphere(F3 center, float angle, fl
 // NextEventEstimation::sample with neePointLight / neeAreaLight / neeDirectionalLight, material/NextEventEstimation.cpp:8-120,
 // and AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41.  The visibility
 // query itself is left to the shadow stage.
-__device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int sampleCount,
+// `nn` = (int)sqrt((double)sampleCount), the stratification grid of the area light (the caller has it per launch).
+__device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int nn,
                                                 uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t vertex)
 {
     NeeSample out;
@@ -187,15 +185,11 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
     out.dir = f3(0, 0, 0);
     out.tmax = 0.0f;
     out.valid = false;
-    const bool hasPoint = sv.nPointLights > 0, hasArea = sv.nAreaLights > 0, hasDir = sv.nDirLights > 0;
-    const float total = (hasArea ? 1.0f : 0.0f) + (hasPoint ? 1.0f : 0.0f) + (hasDir ? 1.0f : 0.0f);
-    const float pointP = (hasPoint ? 1.0f : 0.0f) / total;
-    const float areaP = (hasArea ? 1.0f : 0.0f) / total;
-    const float dirP = (hasDir ? 1.0f : 0.0f) / total;
+    const bool hasDir = sv.nDirLights > 0;
+    const float pointP = sv.neePointP, areaP = sv.neeAreaP;
     const float choice = rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_TYPE);
     if (choice < pointP) {
         const uint32_t n = sv.nPointLights;
-        const float chosenP = 1.0f / n;
         uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevPointLight& L = sv.pointLights[idx];
@@ -204,17 +198,15 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         toLamp = normalized3(toLamp);
         const double geometricFactor = 1.0f / (4.0f * RT_PI * (lampT * lampT));
         const RGBf rad = rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity * geometricFactor);
-        out.radiance = rgb_div_f(rad, pointP * chosenP);
+        out.radiance = rgb_scale_f(rad, sv.neePointScale);   // .divide(pointP * chosenP)
         out.dir = toLamp;
         out.tmax = lampT;
         out.valid = true;
     } else if (choice < pointP + areaP) {
         const uint32_t n = sv.nAreaLights;
-        const float chosenP = 1.0f / n;
         uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevAreaLight& L = sv.areaLights[idx];
-        const int nn = (int)sqrt((double)sampleCount);
         const F3 a = f3(L.a[0], L.a[1], L.a[2]), b = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
         const F3 v1 = (c - a) / (float)nn;
         const F3 v2 = (b - a) / (float)nn;
@@ -225,25 +217,23 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         F3 toLamp = lampPoint - hitpoint;
         const float lampT = norm3(toLamp);
         toLamp = normalized3(toLamp);
-        const RGBf lightIrradiance = area_light_irradiance(L);
-        const RGBf lightRadiance = rgb_div_d(lightIrradiance, RT_PI);
+        const RGBf lightRadiance = rgb(L.radiance[0], L.radiance[1], L.radiance[2]);
         const F3 nrm = f3(L.normal[0], L.normal[1], L.normal[2]);
         const float lampAngle = fmaxf(0.0f, dot3(nrm, -toLamp));
         const float geometricFactor = lampAngle / (lampT * lampT);
         const RGBf irr = rgb_scale_d(lightRadiance, geometricFactor);
-        out.radiance = rgb_div_f(rgb_scale_d(irr, (double)L.area), areaP * chosenP);
+        out.radiance = rgb_scale_f(rgb_scale_d(irr, (double)L.area), sv.neeAreaScale);   // .divide(areaP * chosenP)
         out.dir = toLamp;
         out.tmax = lampT;
         out.valid = true;
     } else if (hasDir) {
         const uint32_t n = sv.nDirLights;
-        const float chosenP = 1.0f / n;
         uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevDirectionalLight& L = sv.dirLights[idx];
         out.dir = sample_steradian_sphere(-f3(L.dir[0], L.dir[1], L.dir[2]), L.angle,
                                           rand_unit(seed, pixel, sample, vertex, DIM_DIR_ALPHA), rand_unit(seed, pixel, sample, vertex, DIM_DIR_BETA));
-        out.radiance = rgb_div_f(rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity), dirP * chosenP);
+        out.radiance = rgb_scale_f(rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity), sv.neeDirScale);   // .divide(dirP * chosenP)
         out.tmax = INFINITY;
         out.valid = true;
     }
