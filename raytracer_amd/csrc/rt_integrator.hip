@@ -463,6 +463,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             if (curVar && j == 0) pool.sHasVar[s] = 1;
             const uint32_t rs = i * M + (passed ? j : 0u);
             const uint32_t vk = (uint32_t)k;
+            const uint64_t rp = rand_prefix(pixel, rs);   // first hashing round of every random number of this vertex
             // The walk from the hit's material to the closure that samples this vertex:
             // MixMaterial::sampleTransport picks a child (material/MixMaterial.cpp:9-26), AddMaterial goes on
             // with its second child and adds its emissive first child to the vertex (material/AddMaterial.cpp:5-17).
@@ -482,7 +483,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
             for (uint32_t level = 0; level < 4; ++level) {
                 const DevMaterial& mm = sv.materials[mi];
                 if (mat_is_mix(mm)) {
-                    const bool choseFirst = rand_unit(st.seed, pixel, rs, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
+                    const bool choseFirst = rand_unit_from(rp, st.seed, vk, DIM_MIX0 + level) > mat_mix_factor(mm, normal, d);
                     walkBits |= (choseFirst ? 2u : 1u) << (2u * level);
                     mi = choseFirst ? mm.first : mm.second;
                 } else if (RICH && mm.type == RTGPU_MAT_ADD) {
@@ -527,7 +528,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 // TransparentMaterial (material/TransparentMaterial.cpp:3-16): straight on, bsdf = identity,
                 // Russian roulette 0.01 (renderer/Renderer.cpp:52, 104-107)
                 done = true;
-                if (!(rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.01f)) {
+                if (!(rand_unit_from(rp, st.seed, vk, DIM_RR) < 0.01f)) {
                     if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.01f)); writeAcc = true; }
                     thr = rgb_div_f(thr, 1.0f - 0.01f);
                     o = hitpoint + (d * 0.0001f);
@@ -565,7 +566,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         const double reflectionWeight = kr, transmissionWeight = 1.0 - kr;
                         reflW = (float)(reflectionWeight / (reflectionWeight + transmissionWeight));
                     }
-                    const bool reflect = rand_unit(st.seed, pixel, rs, vk, DIM_GLASS) < reflW;
+                    const bool reflect = rand_unit_from(rp, st.seed, vk, DIM_GLASS) < reflW;
                     // The reference keeps this state in the node's metadata, and the node that is re-sampled
                     // materialAA times (the sample's first variance vertex) keeps its metadata from pass to pass
                     // (:26-29, renderer/Renderer.cpp:246).  What an earlier pass left behind follows from its
@@ -597,7 +598,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     if (tir && firstVisit) {
                         // total internal reflection, first visit (:62-70): no look for lights, the vertex is an
                         // ordinary bounce and absorbs over its own incoming distance (meta->t is NaN, :173)
-                        if (!(rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.1f)) {
+                        if (!(rand_unit_from(rp, st.seed, vk, DIM_RR) < 0.1f)) {
                             RGBf atten = rgb(1.0f, 1.0f, 1.0f);
                             if (dot3(normal, reflDir) < 0) atten = rgb_pow_d(color, (double)mat.roughness * (double)t);
                             if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
@@ -654,9 +655,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     pushPhoton = passed || j == 0u;
                 } else if (mat.type == RTGPU_MAT_DIFFUSE) {
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
-                    const bool useNEE = rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5f;
+                    const bool useNEE = rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5f;
                     if (useNEE) {
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, pixel, rs, vk);
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);   // what the vertex is worth when the light is hidden
@@ -676,10 +677,10 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                         const Basis3 basis = basis_from(normal);
                         float sx, sy;
                         stratified_square(sampleGrid, (float)sampleI,
-                                          rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_X), rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_Y), sx, sy);
+                                          rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
                         const F3 l = cosine_hemisphere(sx, sy);
                         const F3 dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
-                        const bool terminated = rand_unit(st.seed, pixel, rs, vk, DIM_RR) < 0.1f;
+                        const bool terminated = rand_unit_from(rp, st.seed, vk, DIM_RR) < 0.1f;
                         if (terminated) {
                             done = true;
                         } else {
@@ -710,9 +711,9 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                 } else { // RTGPU_MAT_GLOSSY: GlossyMaterial::sampleTransport / bsdf (material/GlossyMaterial.cpp:68-207)
                     const float roughness = mat.roughness;
                     const bool neeEnabled = roughness > 0;
-                    const bool useNEE = neeEnabled && rand_unit(st.seed, pixel, rs, vk, DIM_NEE_CHOICE) > 0.5;
+                    const bool useNEE = neeEnabled && rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5;
                     if (useNEE) {
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, pixel, rs, vk);
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     } else {
                         float sx, sy;
                         stratified_square(sampleCount, (float)sampleI,
-                                          rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_X), rand_unit(st.seed, pixel, rs, vk, DIM_SQUARE_Y), sx, sy);
+                                          rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
                         const F3 micro = normalized3(vndf_sample(normal, -d, roughness, sx, sy));
                         // getPerfectReflectionDir (GlossyMaterial.cpp:22-25): the double factor narrows to float
                         const F3 sampleDir = d + ((float)(2.0 * (double)dot3(micro, -d)) * micro);

@@ -27,12 +27,21 @@ __host__ __device__ __forceinline__ uint64_t splitmix64(uint64_t z)
 }
 
 // Uniform float in [0,1) with 24 random bits, the stand-in for Rand::unit() (math/FastRandom.h:28-31).
+// The first hashing round only depends on (pixel, sample): code that draws several numbers for one path vertex forms
+// it once (rand_prefix) and finishes each draw with rand_unit_from.
+__host__ __device__ __forceinline__ uint64_t rand_prefix(uint32_t pixel, uint32_t sample)
+{
+    return splitmix64(((uint64_t)pixel << 32) | sample);
+}
+__host__ __device__ __forceinline__ float rand_unit_from(uint64_t prefix, uint32_t seed, uint32_t vertex, uint32_t dim)
+{
+    const uint64_t k2 = ((uint64_t)seed << 32) | (uint64_t)((vertex << 8) | dim);
+    const uint32_t x = (uint32_t)(splitmix64(prefix ^ k2) >> 32);
+    return (float)(x >> 8) * (1.0f / 16777216.0f);
+}
 __host__ __device__ __forceinline__ float rand_unit(uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t vertex, uint32_t dim)
 {
-    const uint64_t k1 = ((uint64_t)pixel << 32) | sample;
-    const uint64_t k2 = ((uint64_t)seed << 32) | (uint64_t)((vertex << 8) | dim);
-    const uint32_t x = (uint32_t)(splitmix64(splitmix64(k1) ^ k2) >> 32);
-    return (float)(x >> 8) * (1.0f / 16777216.0f);
+    return rand_unit_from(rand_prefix(pixel, sample), seed, vertex, dim);
 }
 
 // sampleUniformStratifiedSquare, math/Sampler.h:13-26 (r0, r1 are the two Rand::unit() draws).

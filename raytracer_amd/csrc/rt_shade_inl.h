@@ -177,8 +177,9 @@ __device__ __forceinline__ F3 sample_steradian_sphere(F3 center, float angle, fl
 // and AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41.  The visibility
 // query itself is left to the shadow stage.
 // `nn` = (int)sqrt((double)sampleCount), the stratification grid of the area light (the caller has it per launch).
+// `prefix` = rand_prefix(pixel, sample) of the path vertex.
 __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int nn,
-                                                uint32_t seed, uint32_t pixel, uint32_t sample, uint32_t vertex)
+                                                uint32_t seed, uint64_t prefix, uint32_t vertex)
 {
     NeeSample out;
     out.radiance = rgb(0, 0, 0);
@@ -187,10 +188,10 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
     out.valid = false;
     const bool hasDir = sv.nDirLights > 0;
     const float pointP = sv.neePointP, areaP = sv.neeAreaP;
-    const float choice = rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_TYPE);
+    const float choice = rand_unit_from(prefix, seed, vertex, DIM_LIGHT_TYPE);
     if (choice < pointP) {
         const uint32_t n = sv.nPointLights;
-        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        uint32_t idx = (uint32_t)(rand_unit_from(prefix, seed, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevPointLight& L = sv.pointLights[idx];
         F3 toLamp = f3(L.pos[0], L.pos[1], L.pos[2]) - hitpoint;
@@ -204,14 +205,14 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         out.valid = true;
     } else if (choice < pointP + areaP) {
         const uint32_t n = sv.nAreaLights;
-        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        uint32_t idx = (uint32_t)(rand_unit_from(prefix, seed, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevAreaLight& L = sv.areaLights[idx];
         const F3 a = f3(L.a[0], L.a[1], L.a[2]), b = f3(L.b[0], L.b[1], L.b[2]), c = f3(L.c[0], L.c[1], L.c[2]);
         const F3 v1 = (c - a) / (float)nn;
         const F3 v2 = (b - a) / (float)nn;
-        const float u = 1.0f - sqrtf(rand_unit(seed, pixel, sample, vertex, DIM_AREA_U));
-        const float v = (1.0f - u) * rand_unit(seed, pixel, sample, vertex, DIM_AREA_V);
+        const float u = 1.0f - sqrtf(rand_unit_from(prefix, seed, vertex, DIM_AREA_U));
+        const float v = (1.0f - u) * rand_unit_from(prefix, seed, vertex, DIM_AREA_V);
         const int y = sampleI / nn, x = sampleI % nn;
         const F3 lampPoint = (a + ((u + x) * v1)) + ((v + y) * v2);
         F3 toLamp = lampPoint - hitpoint;
@@ -228,11 +229,11 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         out.valid = true;
     } else if (hasDir) {
         const uint32_t n = sv.nDirLights;
-        uint32_t idx = (uint32_t)(rand_unit(seed, pixel, sample, vertex, DIM_LIGHT_INDEX) * (float)n);
+        uint32_t idx = (uint32_t)(rand_unit_from(prefix, seed, vertex, DIM_LIGHT_INDEX) * (float)n);
         if (idx > n - 1) idx = n - 1;
         const DevDirectionalLight& L = sv.dirLights[idx];
         out.dir = sample_steradian_sphere(-f3(L.dir[0], L.dir[1], L.dir[2]), L.angle,
-                                          rand_unit(seed, pixel, sample, vertex, DIM_DIR_ALPHA), rand_unit(seed, pixel, sample, vertex, DIM_DIR_BETA));
+                                          rand_unit_from(prefix, seed, vertex, DIM_DIR_ALPHA), rand_unit_from(prefix, seed, vertex, DIM_DIR_BETA));
         out.radiance = rgb_scale_f(rgb_scale_d(rgb(L.color[0], L.color[1], L.color[2]), L.intensity), sv.neeDirScale);   // .divide(dirP * chosenP)
         out.tmax = INFINITY;
         out.valid = true;
