@@ -87,6 +87,7 @@ struct SceneView {
     // NextEventEstimation::sample's pick probabilities (material/NextEventEstimation.cpp:8-120), the same for every sample:
     // P(light kind), and 1 / (P(kind) * P(light of that kind)) as rgb_div_f would form it
     float neePointP, neeAreaP, neeDirP, neePointScale, neeAreaScale, neeDirScale;
+    int32_t shadeRegroup;   // shade passes sort a workgroup's paths by their drawn choices (RTGPU_SHADE_REGROUP=0 turns it off)
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal
     int32_t hasGlass;           // some material is glass: paths carry the extra records of a glass vertex

@@ -256,6 +256,56 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
 // that goes on through a shadow ray gets black here and its contribution from the shadow stage.
 constexpr int kShadeBlock = RT_SHADE_BLOCK;
 
+// Which lanes shade together.  Whether a vertex runs next-event estimation or bounces, and towards which kind of light,
+// is drawn per path, so in queue order neighbouring lanes part at every vertex (17 to 33 of 64 lanes were active per
+// instruction).  Those draws only depend on the path's indices, so they are known before anything is loaded: a
+// workgroup sorts its 256 paths by them (bounce / point or directional light / area light) and lane t then shades the
+// t-th path of that order.  A path's result does not depend on the lane that computes it; the guess of the draws' keys
+// below (the material-sample index counts, the vertex after a pending one) only has to be right most of the time.
+struct ShadeItem {
+    uint32_t p, pixel, i, j;
+    bool active;
+};
+template <int BLOCK>
+__device__ __forceinline__ ShadeItem shade_regroup(const SceneView& sv, uint32_t seed, uint32_t M, ShadeItem mine, uint32_t vertex)
+{
+    constexpr int WAVES = BLOCK / 64;
+    constexpr uint32_t CLASSES = 4;   // bounce, light without area, area light, no path
+    __shared__ uint32_t wcnt[CLASSES][WAVES];
+    __shared__ uint32_t ex[4][BLOCK];
+    const int lane = (int)(threadIdx.x & 63u), wave = (int)(threadIdx.x >> 6);
+    uint32_t cls = 3u;
+    if (mine.active) {
+        const uint64_t prefix = rand_prefix(mine.pixel, mine.i * M + mine.j);
+        cls = 0u;
+        if (rand_unit_from(prefix, seed, vertex, DIM_NEE_CHOICE) > 0.5f) {
+            const float choice = rand_unit_from(prefix, seed, vertex, DIM_LIGHT_TYPE);
+            cls = (!(choice < sv.neePointP) && choice < sv.neePointP + sv.neeAreaP) ? 2u : 1u;
+        }
+    }
+    unsigned long long same = 0ull;
+    for (uint32_t c = 0; c < CLASSES; ++c) {
+        const unsigned long long m = __ballot(cls == c);
+        if (lane == 0) wcnt[c][wave] = (uint32_t)__popcll(m);
+        if (cls == c) same = m;
+    }
+    __syncthreads();
+    // position in the order (class, wave, lane)
+    uint32_t pos = (uint32_t)__popcll(same & ((1ull << lane) - 1ull)), nPaths = 0;
+    for (uint32_t c = 0; c < CLASSES; ++c)
+        for (int w = 0; w < WAVES; ++w) {
+            const uint32_t n = wcnt[c][w];
+            if (c < cls || (c == cls && w < wave)) pos += n;
+            if (c < 3u) nPaths += n;
+        }
+    ex[0][pos] = mine.p; ex[1][pos] = mine.pixel; ex[2][pos] = mine.i; ex[3][pos] = mine.j;
+    __syncthreads();
+    ShadeItem out;
+    out.p = ex[0][threadIdx.x]; out.pixel = ex[1][threadIdx.x]; out.i = ex[2][threadIdx.x]; out.j = ex[3][threadIdx.x];
+    out.active = threadIdx.x < nPaths;
+    return out;
+}
+
 template <bool FIRST, bool RICH>
 __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
                                                     const uint32_t* __restrict__ qIn, uint32_t nPaths, const uint32_t* __restrict__ cntIn,
@@ -266,18 +316,33 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
     const uint32_t nIn = FIRST ? nPaths : cntIn[0];
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
-    uint32_t p = 0;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
-    bool active = q < nIn;
-    if (FIRST && active) active = pool.sLive[q / M] != 0;
-    if (active) {
-        p = FIRST ? q : qIn[q];
-        const int maxLen = st.max_path_length;
-        const uint32_t s = p / M, j = p % M;
-        const uint32_t pl = s / G, i = s % G;
+    ShadeItem it;
+    it.p = 0; it.pixel = 0; it.i = 0; it.j = 0;
+    it.active = q < nIn;
+    if (FIRST && it.active) it.active = pool.sLive[q / M] != 0;
+    uint32_t vertexGuess = 0;
+    if (it.active) {
+        it.p = FIRST ? q : qIn[q];
+        const uint32_t s0 = it.p / M;
+        it.j = it.p % M;
+        it.i = s0 % G;
         int px, py;
         bool pvalid;
-        const uint32_t pixel = tile_pixel(st, batch, batch.pixelStart + pl, px, py, pvalid);
+        it.pixel = tile_pixel(st, batch, batch.pixelStart + s0 / G, px, py, pvalid);
+        if (!FIRST) {
+            // the vertex the pass will sample: the one after a vertex that waited for its own ray
+            const uint32_t st0 = __float_as_uint(pool.rayB[it.p].w);
+            vertexGuess = (st0 & ST_K_MASK) + ((st0 & (ST_GLOSSY_PENDING | ST_GLASS_PENDING | ST_RETRACE)) != 0u ? 1u : 0u);
+        }
+    }
+    if (sv.shadeRegroup) it = shade_regroup<kShadeBlock>(sv, st.seed, M, it, vertexGuess);   // uniform branch
+    const bool active = it.active;
+    const uint32_t p = it.p;
+    if (active) {
+        const int maxLen = st.max_path_length;
+        const uint32_t s = p / M, j = it.j, i = it.i;
+        const uint32_t pixel = it.pixel;
         const float4 ra = FIRST ? pool.sA[s] : pool.rayA[p];
         const float4 rb = FIRST ? pool.sB[s] : pool.rayB[p];
         float4 hc;
@@ -438,17 +503,19 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
 
         if (!done) {
             // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
-            const DevInstance& in = sv.inst[inst];
+            // Everything the vertex needs from the scene is asked for here, side by side: the material index of the triangle,
+            // the instance record and the vertex normals.  (Fetched where they are first used, behind the branches on the
+            // material type, they queue up one behind the other, and with four waves per SIMD that wait is what the pass
+            // spends its time on.)  In a one-mesh scene the instance record is the same for every lane and comes through
+            // the scalar cache.
+            const DevInstance& in = sv.inst[sv.singleMesh ? 0u : inst];
             const uint32_t slot = __float_as_uint(hc.y);
             const float beta = hc.z, gamma = hc.w;
+            uint32_t tm = kInvalid;
+            if (sv.triMaterial) tm = sv.triMaterial[slot != kInvalid ? slot : 0u];   // uniform branch
+            F3 normal = sv.singleMesh ? hit_normal(sv, sv.inst[0], o, d, t, slot, beta, gamma) : hit_normal(sv, in, o, d, t, slot, beta, gamma);
             uint32_t mi = in.material;
-            if (slot != kInvalid && sv.triMaterial) {
-                const uint32_t tm = sv.triMaterial[slot];
-                if (tm != kInvalid) mi = tm;
-            }
-            // the shading normal is needed up front only when a mix factor depends on the hit
-            F3 normal = f3(0.0f, 0.0f, 0.0f);
-            if (sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
+            if (slot != kInvalid && tm != kInvalid) mi = tm;
             // PhotonMapMode::full: once `pmDepth` earlier vertices were diffuse, a diffuse closure reads the map
             // (material/DiffuseMaterial.cpp:40-54) and has no variance (:228-247)
             const uint32_t diffuseCount = (state & ST_DIFFUSE_MASK) >> ST_DIFFUSE_SHIFT;
@@ -537,7 +604,6 @@ __global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool p
                     pushExt = true;
                 }
             } else {
-                if (!sv.hasFresnelMix) normal = hit_normal(sv, in, o, d, t, slot, beta, gamma);
                 // the normal a diffuse / glossy closure shades with (DiffuseMaterial.cpp:33-37, GlossyMaterial.cpp:81-85);
                 // Glossy's test of the sampled direction against the surface keeps the hit's own normal (:114)
                 const F3 surfaceNormal = normal;
