@@ -307,7 +307,10 @@ __device__ __forceinline__ ShadeItem shade_regroup(const SceneView& sv, uint32_t
 }
 
 template <bool FIRST, bool RICH>
-__global__ __launch_bounds__(kShadeBlock) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
+// five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took 98-111 of its own
+// accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and lose, and so does
+// five for the RICH variants)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
                                                     const uint32_t* __restrict__ qIn, uint32_t nPaths, const uint32_t* __restrict__ cntIn,
                                                     uint32_t* __restrict__ qExt, uint32_t* __restrict__ cnt)
 {
