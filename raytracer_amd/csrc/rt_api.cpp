@@ -697,6 +697,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     }
     v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 1;
     v.gatherBudget = std::getenv("RTGPU_GATHER_BUDGET") ? (uint32_t)std::strtoul(std::getenv("RTGPU_GATHER_BUDGET"), nullptr, 10) : 192u;
+    v.skipBlackShadow = std::getenv("RTGPU_SKIP_BLACK_SHADOW") ? std::atoi(std::getenv("RTGPU_SKIP_BLACK_SHADOW")) : 1;
     v.shadeRegroup = std::getenv("RTGPU_SHADE_REGROUP") ? std::atoi(std::getenv("RTGPU_SHADE_REGROUP")) : 1;
     v.stealLeafPct = std::getenv("RTGPU_STEAL_LEAF_PCT") ? std::atoi(std::getenv("RTGPU_STEAL_LEAF_PCT")) : 48;
     v.refTopRoot = (refTop && rtop.rootIsLeaf) ? encode_top_leaf(0, nInst) : 0;

@@ -87,6 +87,8 @@ struct SceneView {
     // NextEventEstimation::sample's pick probabilities (material/NextEventEstimation.cpp:8-120), the same for every sample:
     // P(light kind), and 1 / (P(kind) * P(light of that kind)) as rgb_div_f would form it
     float neePointP, neeAreaP, neeDirP, neePointScale, neeAreaScale, neeDirScale;
+    int32_t skipBlackShadow;   // a next-event sample whose value is exactly zero before the visibility test (light behind the surface, light
+                               // facing away) is not traced: seen or hidden, the path's value is the same (RTGPU_SKIP_BLACK_SHADOW=0 traces them)
     int32_t shadeRegroup;   // shade passes sort a workgroup's paths by their drawn choices (RTGPU_SHADE_REGROUP=0 turns it off)
     int32_t hasEnv;
     int32_t hasFresnelMix;      // some material is a Fresnel mix: mix factors (and hasVariance) need the hit's normal

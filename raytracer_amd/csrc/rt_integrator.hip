@@ -740,7 +740,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                             outTmax = ns.tmax;
                             outAux = f3(c.r, c.g, c.b);
                             writeAux = true;
-                            pushShadow = true;
+                            // a sample worth exactly nothing (the light is behind the surface or faces away) leaves the path's value
+                            // what it is when the light is hidden: no query (NaN or infinite values are not zero and are traced)
+                            pushShadow = !(sv.skipBlackShadow && value.r == 0.0f && value.g == 0.0f && value.b == 0.0f);
                         }
                     } else {
                         const Basis3 basis = basis_from(normal);
@@ -797,7 +799,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                             outTmax = ns.tmax;
                             outAux = f3(c.r, c.g, c.b);
                             writeAux = true;
-                            pushShadow = true;
+                            pushShadow = !(sv.skipBlackShadow && neeRadiance.r == 0.0f && neeRadiance.g == 0.0f && neeRadiance.b == 0.0f);
                         }
                     } else {
                         float sx, sy;

@@ -291,8 +291,9 @@ def test_render_matches_oracle_at_matched_streams(name, G, M, W, H):
     mse = float(np.mean((img - ref) ** 2))
     assert 10 * np.log10(float(ref.max()) ** 2 / max(mse, 1e-30)) >= 80.0
     assert stats.primary_rays == rstats.primary_rays == W * H * G
-    # the wavefront skips queries whose result cannot contribute (last path vertex), never adds any
-    assert stats.shadow_rays <= rstats.shadow_rays and stats.shadow_rays >= 0.97 * rstats.shadow_rays
+    # the wavefront skips queries whose result cannot contribute (last path vertex, next-event samples worth exactly zero),
+    # never adds any; test_black_shadow_rays_are_skipped_without_changing_a_pixel holds the count without the second kind
+    assert stats.shadow_rays <= rstats.shadow_rays
     assert stats.extension_rays <= rstats.extension_rays * 1.0001 and stats.extension_rays >= 0.97 * rstats.extension_rays
     if (name, G, M) == ("box", 4, 4):
         gold = np.load(os.path.join(GOLDEN, "box_render_48x36_g4_m4_seed11.npz"))
@@ -486,6 +487,27 @@ def test_two_host_threads_on_one_scene_take_turns():
                 assert np.array_equal(got[(k, rep)], want[k])
                 for f in ("t", "prim", "inst"):
                     assert np.array_equal(got[("hits", k, rep)][f], want_hits[f])
+
+
+@pytest.mark.parametrize("name", ["box", "mirror", "all"])
+def test_black_shadow_rays_are_skipped_without_changing_a_pixel(name, monkeypatch):
+    """A next-event sample whose value is exactly zero before the visibility test (light behind the surface, area light
+    facing away) is not traced.  With the skip turned off the ray count is the reference's (up to last-vertex queries),
+    with it on the frame is the same bit for bit."""
+    sc, cam_m, yfov = scenes.sun_scene(name) if name == "all" else scenes.box_scene(with_mirror=(name == "mirror"))
+    W, H = 48, 36
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=11)
+    _, rstats = oracle.OracleScene(sc).render(cam, st)
+    monkeypatch.setenv("RTGPU_SKIP_BLACK_SHADOW", "0")
+    with api.Scene(sc) as g:
+        img_all, stats_all = api.Renderer().render(g, cam, st)
+    monkeypatch.delenv("RTGPU_SKIP_BLACK_SHADOW")
+    with api.Scene(sc) as g:
+        img, stats = api.Renderer().render(g, cam, st)
+    assert stats_all.shadow_rays <= rstats.shadow_rays and stats_all.shadow_rays >= 0.97 * rstats.shadow_rays
+    assert np.array_equal(img, img_all)
+    assert stats.shadow_rays < stats_all.shadow_rays and stats.extension_rays == stats_all.extension_rays
 
 
 def test_render_work_counts_and_same_image():
