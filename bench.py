@@ -57,7 +57,8 @@ def roofline(alg_bytes, kernel_ms, scene_bytes, kernel, extra=None):
 
 
 def attach_counters(rl, c, src, per):
-    """Quotes committed PMC figures (same kernel, same workload) beside a live roofline."""
+    """Quotes committed PMC figures (same kernel, same workload) beside a live roofline.  The counters belong to the build
+    the profile was taken from (its commit is in the summary file), the times beside them to this run."""
     rl["traffic"] = c.get("hbm_bytes_per_" + per)
     rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
     if c.get("hbm_GBps"):
@@ -71,7 +72,8 @@ def committed_counters(tag):
     passes of this program; NOT measured in this run)."""
     path = os.path.join(HERE, "profiles", tag + "_pmc_summary.json")
     try:
-        return json.load(open(path)), os.path.relpath(path, HERE)
+        summary = json.load(open(path))
+        return summary, os.path.relpath(path, HERE) + " taken at commit " + str(summary.get("commit", "?"))
     except Exception:
         return None, None
 
