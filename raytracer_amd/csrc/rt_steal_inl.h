@@ -239,11 +239,11 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 const uint32_t slot = triBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
                 const float4* tp = tri_ptr(sv, slot);
                 const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                float t, be, ga;
+                float t;
 #ifdef RT_DEV_STATS
                 dsLeafIt += 1.0f / (float)__popcll(wave_ballot(true));
 #endif
-                if (tri_test(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, be, ga) && t <= hlim) {
+                if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t) && t <= hlim) {
                     if (ANY) {
                         atomicMin(&L.best[howner], 0ull);
                     } else {
@@ -497,8 +497,8 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     const uint32_t slot = htriBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
                     const float4* tp = tri_ptr(sv, slot);
                     const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                    float t, be, ga;
-                    if (tri_test(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, be, ga) && t <= hlim) {
+                    float t;
+                    if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t) && t <= hlim) {
                         if (ANY) {
                             atomicMin(&L.best[howner], 0ull);
                         } else {
