@@ -101,6 +101,21 @@ int main(int argc, char** argv)
         std::printf("traceRay +y: %s\n", hitUp ? "hit" : "miss");
         std::printf("testVisibility -x within 0.5: %d, within 2: %d\n", (int)scene.testVisibility(origin, left, 0.5f), (int)scene.testVisibility(origin, left, 2.0f));
 
+        // ---- a batch of rays kept in page-locked arrays (rtgpu::HostArray): the same answers without staging copies ----
+        {
+            const uint64_t n = 1000;
+            rtgpu::HostArray<float> o(3 * n), d(3 * n);
+            rtgpu::HostArray<rtgpu_hit> hits(n);
+            for (uint64_t i = 0; i < n; ++i) {
+                o[3 * i] = 0; o[3 * i + 1] = 1; o[3 * i + 2] = 0;
+                d[3 * i] = (i & 1) ? 1.0f : -1.0f; d[3 * i + 1] = 0; d[3 * i + 2] = 0;
+            }
+            scene.traceRays(o.data(), d.data(), n, hits.data());
+            uint64_t ok = 0;
+            for (uint64_t i = 0; i < n; ++i) ok += hits[i].inst == ((i & 1) ? 2u : 1u) && hits[i].t == 1.0f;
+            std::printf("traceRays on page-locked arrays: %llu of %llu as expected\n", (unsigned long long)ok, (unsigned long long)n);
+        }
+
         // ---- Renderer::render ----
         const double cameraTransform[16] = {1, 0, 0, 0.0,  0, 1, 0, 2.0,  0, 0, 1, 7.0,  0, 0, 0, 1};  // looks down -z from (0, 2, 7)
         rtgpu_camera camera;

@@ -31,6 +31,7 @@ EXPORTS = [
     "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
     "rtgpu_comm_unique_id", "rtgpu_comm_create", "rtgpu_comm_destroy", "rtgpu_tile_buffer_floats", "rtgpu_render_tiles_device",
     "rtgpu_gather_tiles_device", "rtgpu_scatter_tiles_device", "rtgpu_scene_replicate", "rtgpu_render_work_device", "rtgpu_render_profile_device", "rtgpu_render_device_static",
+    "rtgpu_host_alloc", "rtgpu_host_free",
 ]
 
 _lib = None
@@ -65,6 +66,8 @@ def lib():
     L.rtgpu_scene_destroy.argtypes = [vp]
     L.rtgpu_scene_destroy.restype = None
     L.rtgpu_trace_closest.argtypes = [vp, fp, fp, C.c_uint64, vp]
+    L.rtgpu_host_alloc.argtypes = [C.POINTER(vp), C.c_uint64]
+    L.rtgpu_host_free.argtypes = [vp]
     L.rtgpu_trace_closest_device.argtypes = [vp, vp, vp, C.c_uint64, vp, vp]
     L.rtgpu_trace_any.argtypes = [vp, fp, fp, fp, C.c_uint64, u8p]
     L.rtgpu_trace_any_device.argtypes = [vp, vp, vp, vp, C.c_uint64, vp, vp]
@@ -234,11 +237,16 @@ class Scene:
         return out
 
     # ---- Scene::traceRay / traceRays ---------------------------------------------------
-    def trace_rays(self, origins, dirs) -> np.ndarray:
+    def trace_rays(self, origins, dirs, out=None) -> np.ndarray:
+        """Closest hits of a batch of rays in host arrays.  `out` (a C-contiguous HIT_DTYPE array of the batch's length)
+        is filled and returned when given: a caller that keeps its result array pays no page faults for a fresh one."""
         o, d = _f32(origins), _f32(dirs)
         if o.shape != d.shape:
             raise ValueError("origins and directions must have the same shape")
-        out = np.empty(o.shape[0], dtype=abi.HIT_DTYPE)
+        if out is None:
+            out = np.empty(o.shape[0], dtype=abi.HIT_DTYPE)
+        elif out.dtype != abi.HIT_DTYPE or out.shape != (o.shape[0],) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous HIT_DTYPE array with one record per ray")
         _check(lib().rtgpu_trace_closest(self._h, o.ctypes.data_as(abi.c_float_p), d.ctypes.data_as(abi.c_float_p),
                                          o.shape[0], C.c_void_p(out.ctypes.data)))
         return out
@@ -254,18 +262,48 @@ class Scene:
         _check(lib().rtgpu_trace_closest_count_device(self._h, _ptr(d_origins), _ptr(d_dirs), int(n), _ptr(d_counts), _stream_ptr(stream)))
 
     # ---- Scene::testVisibility ---------------------------------------------------------
-    def test_visibility(self, origins, dirs, max_t) -> np.ndarray:
+    def test_visibility(self, origins, dirs, max_t, out=None) -> np.ndarray:
         o, d = _f32(origins), _f32(dirs)
         t = _f32(np.broadcast_to(np.asarray(max_t, dtype=np.float32), (o.shape[0],)), cols=0)
         if o.shape != d.shape:
             raise ValueError("origins and directions must have the same shape")
-        out = np.empty(o.shape[0], dtype=np.uint8)
+        if out is None:
+            out = np.empty(o.shape[0], dtype=np.uint8)
+        elif out.dtype != np.uint8 or out.shape != (o.shape[0],) or not out.flags.c_contiguous:
+            raise ValueError("out must be a C-contiguous uint8 array with one entry per ray")
         _check(lib().rtgpu_trace_any(self._h, o.ctypes.data_as(abi.c_float_p), d.ctypes.data_as(abi.c_float_p),
                                      t.ctypes.data_as(abi.c_float_p), o.shape[0], out.ctypes.data_as(abi.c_u8_p)))
         return out
 
     def test_visibility_device(self, d_origins, d_dirs, d_tmax, n, d_occluded, stream=None):
         _check(lib().rtgpu_trace_any_device(self._h, _ptr(d_origins), _ptr(d_dirs), _ptr(d_tmax), int(n), _ptr(d_occluded), _stream_ptr(stream)))
+
+
+class _HostBlock:
+    """Owner of one rtgpu_host_alloc block; the arrays made from it keep it alive."""
+
+    def __init__(self, nbytes):
+        p = C.c_void_p()
+        _check(lib().rtgpu_host_alloc(C.byref(p), int(nbytes)))
+        self.ptr = p.value
+        self.nbytes = int(nbytes)
+        self._free = lib().rtgpu_host_free      # kept here: module globals may be gone when the last block dies at exit
+        self.__array_interface__ = {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 3}
+
+    def __del__(self):
+        if getattr(self, "ptr", None):
+            self._free(self.ptr)
+            self.ptr = None
+
+
+def host_empty(shape, dtype=np.float32) -> np.ndarray:
+    """A C-contiguous numpy array in page-locked host memory (rtgpu_host_alloc); freed when the last view of it goes.
+    Scene.trace_rays / test_visibility move such arrays across PCIe without staging copies."""
+    dt = np.dtype(dtype)
+    shape = (int(shape),) if np.isscalar(shape) else tuple(int(x) for x in shape)
+    n = int(np.prod(shape, dtype=np.int64))
+    block = _HostBlock(max(1, n * dt.itemsize))
+    return np.asarray(block)[: n * dt.itemsize].view(dt).reshape(shape)
 
 
 def generate_primary_device(cam: abi.Camera, st: abi.RenderSettings, sample_index, d_origins, d_dirs, stream=None):

@@ -225,11 +225,21 @@ struct HostPipe {
         hipStream_t stream = nullptr;
     };
     std::vector<Slot> slots;
+    // Callers whose arrays are page-locked already (rtgpu_host_alloc, hipHostMalloc, hipHostRegister) need no staging:
+    // the DMA engines read and write their arrays.  These slots hold device buffers only.
+    static constexpr uint64_t kDirectChunk = 1ull << 17;
+    static constexpr size_t kDirectSlots = 4;
+    std::vector<Slot> direct;
 };
 
 void destroy_host_pipe(HostPipe* p)
 {
     if (!p) return;
+    for (HostPipe::Slot& s : p->direct) {
+        if (s.stream) (void)hipStreamDestroy(s.stream);
+        if (s.devIn) (void)hipFree(s.devIn);
+        if (s.devOut) (void)hipFree(s.devOut);
+    }
     for (HostPipe::Slot& s : p->slots) {
         if (s.stream) (void)hipStreamDestroy(s.stream);
         if (s.pinIn) (void)hipHostFree(s.pinIn);
@@ -308,6 +318,61 @@ int host_pipeline(const rtgpu_scene& scene, uint64_t n, size_t outBytesPerRay, c
     worker(0);
     for (std::thread& t : threads) t.join();
     for (hipError_t e : errs) RT_HIP(e);
+    return RTGPU_OK;
+}
+
+// True when [p, p + bytes) is host memory the HIP runtime has page-locked.
+bool host_range_pinned(const void* p, size_t bytes)
+{
+    const char* ends[2] = {(const char*)p, (const char*)p + (bytes ? bytes - 1 : 0)};
+    for (const char* q : ends) {
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, q) != hipSuccess) {
+            (void)hipGetLastError();   // an ordinary host pointer is reported as an error by some runtimes: not ours to keep
+            return false;
+        }
+        if (a.type != hipMemoryTypeHost) return false;
+    }
+    return true;
+}
+
+// The pipeline for page-locked caller arrays: no staging copies and no helper threads; chunks go round a few streams,
+// each with its own device buffers (stream order keeps a buffer's next upload behind its last download).
+template <typename Launch>
+int direct_pipeline(const rtgpu_scene& scene, uint64_t n, const float* origins, const float* dirs, const float* tmax, void* out,
+                    size_t outBytesPerRay, const Launch& launch)
+{
+    using rt::HostPipe;
+    std::lock_guard<std::mutex> cacheLock(scene.cacheMutex);
+    if (!scene.hostPipe) scene.hostPipe = new HostPipe();
+    HostPipe& hp = *scene.hostPipe;
+    while (hp.direct.size() < HostPipe::kDirectSlots) {
+        HostPipe::Slot s;
+        hipError_t e = hipStreamCreateWithFlags(&s.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.devIn, HostPipe::kDirectChunk * HostPipe::kInBytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&s.devOut, HostPipe::kDirectChunk * HostPipe::kOutBytes);
+        hp.direct.push_back(s);   // kept even when incomplete: destroy_host_pipe frees what there is
+        RT_HIP(e);
+    }
+    // chunks of 2^17 rays measured best for 2 073 600 rays (2^16: 1.59 ms, 2^17: 1.48 ms, 2^18: 1.59 ms, 2^19: 1.74 ms): small
+    // enough for the two DMA directions to overlap, large enough to keep the runtime calls per ray few
+    const uint64_t chunk = HostPipe::kDirectChunk;
+    hipError_t e = hipSuccess;
+    uint64_t c = 0;
+    for (uint64_t first = 0; first < n && e == hipSuccess; first += chunk, ++c) {
+        HostPipe::Slot& s = hp.direct[c % HostPipe::kDirectSlots];
+        const uint64_t m = std::min(chunk, n - first);
+        e = hipMemcpyAsync(s.devIn, origins + 3 * first, m * 12, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(s.devIn + m * 12, dirs + 3 * first, m * 12, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess && tmax) e = hipMemcpyAsync(s.devIn + m * 24, tmax + first, m * 4, hipMemcpyHostToDevice, s.stream);
+        if (e == hipSuccess) e = launch(s, m);
+        if (e == hipSuccess) e = hipMemcpyAsync((char*)out + first * outBytesPerRay, s.devOut, m * outBytesPerRay, hipMemcpyDeviceToHost, s.stream);
+    }
+    for (HostPipe::Slot& s : hp.direct) {
+        const hipError_t e2 = hipStreamSynchronize(s.stream);
+        if (e == hipSuccess) e = e2;
+    }
+    RT_HIP(e);
     return RTGPU_OK;
 }
 
@@ -791,6 +856,22 @@ struct DevBuf {
 };
 } // namespace
 
+int rtgpu_host_alloc(void** out_ptr, uint64_t bytes)
+{
+    if (!out_ptr) return fail(RTGPU_ERR_INVALID_ARGUMENT, "out_ptr is null");
+    *out_ptr = nullptr;
+    if (bytes == 0) return fail(RTGPU_ERR_INVALID_ARGUMENT, "cannot allocate 0 bytes");
+    RT_HIP(hipHostMalloc(out_ptr, (size_t)bytes, hipHostMallocPortable));
+    return RTGPU_OK;
+}
+
+int rtgpu_host_free(void* ptr)
+{
+    if (!ptr) return RTGPU_OK;
+    RT_HIP(hipHostFree(ptr));
+    return RTGPU_OK;
+}
+
 int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const float* dirs, uint64_t n, rtgpu_hit* out_hits)
 {
     if (!scene) return fail(RTGPU_ERR_INVALID_ARGUMENT, "scene is null");
@@ -799,15 +880,18 @@ int rtgpu_trace_closest(const rtgpu_scene* scene, const float* origins, const fl
     RT_HIP(hipSetDevice(scene->device));
     using rt::HostPipe;
     return rt::guarded([&]() -> int {
+        const auto launch = [&](HostPipe::Slot& s, uint64_t m) {
+            return rt::launch_trace_closest(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), m, (rtgpu_hit*)s.devOut, nullptr, s.stream);
+        };
+        if (host_range_pinned(origins, n * 12) && host_range_pinned(dirs, n * 12) && host_range_pinned(out_hits, n * sizeof(rtgpu_hit)))
+            return direct_pipeline(*scene, n, origins, dirs, nullptr, out_hits, sizeof(rtgpu_hit), launch);
         return host_pipeline(*scene, n, sizeof(rtgpu_hit),
             [&](HostPipe::Slot& s, uint64_t first, uint64_t m) -> size_t {
                 std::memcpy(s.pinIn, origins + 3 * first, m * 12);
                 std::memcpy(s.pinIn + m * 12, dirs + 3 * first, m * 12);
                 return (size_t)m * 24;
             },
-            [&](HostPipe::Slot& s, uint64_t m) {
-                return rt::launch_trace_closest(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), m, (rtgpu_hit*)s.devOut, nullptr, s.stream);
-            },
+            launch,
             [&](HostPipe::Slot& s, uint64_t first, uint64_t m) { std::memcpy(out_hits + first, s.pinOut, m * sizeof(rtgpu_hit)); });
     });
 }
@@ -820,6 +904,12 @@ int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float*
     RT_HIP(hipSetDevice(scene->device));
     using rt::HostPipe;
     return rt::guarded([&]() -> int {
+        const auto launch = [&](HostPipe::Slot& s, uint64_t m) {
+            return rt::launch_trace_any(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), (const float*)(s.devIn + m * 24), m,
+                                        (uint8_t*)s.devOut, s.stream);
+        };
+        if (host_range_pinned(origins, n * 12) && host_range_pinned(dirs, n * 12) && host_range_pinned(tmax, n * 4) && host_range_pinned(out_occluded, n))
+            return direct_pipeline(*scene, n, origins, dirs, tmax, out_occluded, 1, launch);
         return host_pipeline(*scene, n, 1,
             [&](HostPipe::Slot& s, uint64_t first, uint64_t m) -> size_t {
                 std::memcpy(s.pinIn, origins + 3 * first, m * 12);
@@ -827,10 +917,7 @@ int rtgpu_trace_any(const rtgpu_scene* scene, const float* origins, const float*
                 std::memcpy(s.pinIn + m * 24, tmax + first, m * 4);
                 return (size_t)m * 28;
             },
-            [&](HostPipe::Slot& s, uint64_t m) {
-                return rt::launch_trace_any(scene->view, (const float*)s.devIn, (const float*)(s.devIn + m * 12), (const float*)(s.devIn + m * 24), m,
-                                            (uint8_t*)s.devOut, s.stream);
-            },
+            launch,
             [&](HostPipe::Slot& s, uint64_t first, uint64_t m) { std::memcpy(out_occluded + first, s.pinOut, m); });
     });
 }

@@ -44,6 +44,7 @@ def test_cxx_host_program_matches_the_python_mirror(tmp_path):
     # Scene::traceRay as in raytracer/test/BVH.cpp:18-49 (instances 1 and 2 are the spheres at x = -2 / +2)
     assert "traceRay -x: inst 1 t 1\n" in log and "traceRay +x: inst 2 t 1\n" in log and "traceRay +y: miss" in log
     assert "testVisibility -x within 0.5: 0, within 2: 1" in log
+    assert "traceRays on page-locked arrays: 1000 of 1000 as expected" in log
     assert "invalid_argument: scene has no materials" in log
     m = re.search(r"render 64x48: (\d+) primary, (\d+) extension, (\d+) shadow rays, .* (\d+) progress calls", log)
     assert m and int(m.group(1)) == W * H * G and int(m.group(4)) >= 2

@@ -152,6 +152,38 @@ def test_empty_and_ragged_batches():
             assert np.array_equal(g.test_visibility(o, d, tmax), S.trace_any(o, d, tmax))
 
 
+def test_page_locked_caller_arrays_give_the_same_results():
+    """rtgpu_host_alloc arrays take the pipeline without staging copies: several chunks (ragged last one), closest and
+    any hit, against the oracle and bit for bit against the staged pipeline; an array that is only partly page-locked
+    (one argument pageable) takes the staged path."""
+    sc, _, _ = scenes.interior_scene(detail=0.3)
+    S = oracle.OracleScene(sc)
+    n = 3 * (1 << 17) + 1234
+    o, d = scenes.random_rays(n, (0.5, 0.5, 0.5), (23, 8, 9), seed=11)
+    with api.Scene(sc) as g:
+        staged = g.trace_rays(o, d)
+        po, pd = api.host_empty(o.shape), api.host_empty(d.shape)
+        pout = api.host_empty(n, abi.HIT_DTYPE)
+        po[:] = o
+        pd[:] = d
+        pout.view(np.uint8)[:] = 0xAB
+        got = g.trace_rays(po, pd, pout)
+        assert got is pout and np.array_equal(pout.view(np.uint8), staged.view(np.uint8))
+        sel = np.arange(0, n, 37)
+        assert_hits_match(S, pout[sel], o[sel], d[sel])
+        tmax = np.where(np.arange(n) % 2 == 0, staged["t"] * 0.5, staged["t"] * 1.5).astype(np.float32)
+        ptm, pocc = api.host_empty(n), api.host_empty(n, np.uint8)
+        ptm[:] = tmax
+        pocc[:] = 7
+        occ = g.test_visibility(o, d, tmax)
+        assert g.test_visibility(po, pd, ptm, pocc) is pocc and np.array_equal(pocc, occ)
+        assert np.array_equal(occ[sel], S.trace_any(o[sel], d[sel], tmax[sel]))
+        mixed = g.trace_rays(po, d, pout)          # pageable directions: staged pipeline into the page-locked result
+        assert np.array_equal(mixed.view(np.uint8), staged.view(np.uint8))
+        with pytest.raises(ValueError):
+            g.trace_rays(po, pd, np.zeros(n - 1, abi.HIT_DTYPE))
+
+
 def test_deep_stack_rays_along_a_row_of_triangles():
     """Rays that pierce every box of a deep tree (524 288 small triangles in a row, rays along the row) need
     more pending subtrees than the LDS part of the traversal stack holds: the private-memory overflow path
