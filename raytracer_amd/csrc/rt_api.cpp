@@ -388,7 +388,7 @@ void rtgpu_scene::release()
     rt::destroy_host_pipe(hostPipe);
     hostPipe = nullptr;
     arrays.clear();
-    const void* ptrs[] = {view.nodes, view.refNodes, view.tris, view.triIds, view.inst, view.instOrder, view.vertNormals, view.triMaterial,
+    const void* ptrs[] = {view.nodes, view.refNodes, view.tris, view.triIds, view.inst, view.instOrder, view.shadeRecs,
                           view.materials, view.pointLights, view.areaLights, view.dirLights, view.vertUV, view.textures, view.texels, view.instFwd, view.envMap, view.kdPos, view.kdNormal, view.kdEnergy};
     for (const void* p : ptrs)
         if (p) (void)hipFree(const_cast<void*>(p));
@@ -545,15 +545,13 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     // ---- mesh trees ------------------------------------------------------------------------
     std::vector<Node128> nodes;
     std::vector<TriRec> tris;
-    std::vector<uint32_t> triIds, triMat;
-    std::vector<float> vertNormals;
+    std::vector<uint32_t> triIds;
+    std::vector<float> shadeRecs;   // 12 floats per leaf slot: 9 of the vertex normals, the material id's bits, 2 unused
     std::vector<uint32_t> meshRoot(desc->n_meshes), meshTriBase(desc->n_meshes);
     rtgpu_scene_info info{};
-    bool anyTriMat = false, anyUV = false;
-    for (uint32_t m = 0; m < desc->n_meshes; ++m) {
-        if (desc->meshes[m].tri_material) anyTriMat = true;
+    bool anyUV = false;
+    for (uint32_t m = 0; m < desc->n_meshes; ++m)
         if (desc->meshes[m].texcoords) anyUV = true;
-    }
     if (desc->n_textures == 0) anyUV = false;   // texture coordinates are only read by texture lookups
     std::vector<float> vertUV;
     for (uint32_t m = 0; m < desc->n_meshes; ++m) {
@@ -580,8 +578,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         const size_t base = tris.size();
         tris.resize(base + md.n_triangles);
         triIds.resize(base + md.n_triangles);
-        vertNormals.resize((base + md.n_triangles) * 9);
-        if (anyTriMat) triMat.resize(base + md.n_triangles);
+        shadeRecs.resize((base + md.n_triangles) * 12);
         if (anyUV) vertUV.resize((base + md.n_triangles) * 6, 0.0f);
         parallel_for(md.n_triangles, threads, [&](size_t b, size_t e) {
             for (size_t s = b; s < e; ++s) {
@@ -600,11 +597,13 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
                 r.c2 = r.e1x * r.e2y - r.e1y * r.e2x;
                 tris[base + s] = r;
                 triIds[base + s] = tri;
-                float* vn = vertNormals.data() + (base + s) * 9;
+                float* vn = shadeRecs.data() + (base + s) * 12;
                 std::memcpy(vn, md.normals + 3 * (size_t)i0, 12);
                 std::memcpy(vn + 3, md.normals + 3 * (size_t)i1, 12);
                 std::memcpy(vn + 6, md.normals + 3 * (size_t)i2, 12);
-                if (anyTriMat) triMat[base + s] = md.tri_material ? md.tri_material[tri] : kInvalid;
+                const uint32_t triMat = md.tri_material ? md.tri_material[tri] : kInvalid;
+                std::memcpy(vn + 9, &triMat, 4);
+                vn[10] = 0.0f; vn[11] = 0.0f;
                 if (anyUV) {
                     float* uv = vertUV.data() + (base + s) * 6;
                     if (md.texcoords) {
@@ -740,7 +739,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     using SV = SceneView;
     if ((rc = upload(*sc, &SV::nodes, nodes, bytes)) || (rc = upload(*sc, &SV::refNodes, rtop.nodes, bytes)) || (rc = upload(*sc, &SV::tris, tris, bytes)) ||
         (rc = upload(*sc, &SV::triIds, triIds, bytes)) || (rc = upload(*sc, &SV::inst, inst, bytes)) || (rc = upload(*sc, &SV::instOrder, instOrder, bytes)) ||
-        (rc = upload(*sc, &SV::vertNormals, vertNormals, bytes)) || (rc = upload(*sc, &SV::triMaterial, triMat, bytes)) ||
+        (rc = upload(*sc, &SV::shadeRecs, shadeRecs, bytes)) ||
         (rc = upload(*sc, &SV::materials, mats, bytes)) || (rc = upload(*sc, &SV::pointLights, pls, bytes)) ||
         (rc = upload(*sc, &SV::areaLights, als, bytes)) || (rc = upload(*sc, &SV::dirLights, dls, bytes)) ||
         (rc = upload(*sc, &SV::vertUV, vertUV, bytes)) || (rc = upload(*sc, &SV::textures, texs, bytes)) || (rc = upload(*sc, &SV::texels, texels, bytes)) ||

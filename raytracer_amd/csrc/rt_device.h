@@ -73,8 +73,9 @@ struct SceneView {
     uint32_t gatherBudget;      // tree nodes a photon gather may look at in its first attempt
     int32_t stealLeafPct;       // a wave runs a leaf step once this share (of 128) of its busy lanes waits at a leaf
     // shade stage
-    const float* vertNormals;   // per leaf slot: 3 vertex normals (9 floats)
-    const uint32_t* triMaterial; // per leaf slot material id, or kInvalid -> instance material
+    const float4* shadeRecs;    // per leaf slot, 3 x float4: the three vertex normals (9 floats), the triangle's material id
+                                // (bits; kInvalid -> instance material), two unused words -- what a vertex needs of its
+                                // triangle in one 48-byte record (one or two cache lines instead of three)
     const DevMaterial* materials;
     const DevPointLight* pointLights;
     const DevAreaLight* areaLights;

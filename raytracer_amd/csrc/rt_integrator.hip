@@ -71,12 +71,23 @@ constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
 // arrays would each cost a memory transaction of their own).
+// One of the four 16-byte records every pass touches.  They share a 64-byte block per path (block[path][4]): a path
+// that is reached through an index queue -- at a scattered address -- then costs one cache line, not four.
+struct PathField {
+    float4* base;
+#ifdef RT_POOL_SOA
+    __device__ __forceinline__ float4& operator[](size_t p) const { return base[p]; }
+#else
+    __device__ __forceinline__ float4& operator[](size_t p) const { return base[p * 4]; }
+#endif
+};
+
 struct Pool {
-    float4* rayA;         // per path: origin of the pending ray / of the ray that produced the current hit; w = shadow-ray limit
-    float4* rayB;         // per path: direction; w = state bits
-    float4* hit;          // per path: t, leaf slot (bits), beta, gamma of the current vertex
+    PathField rayA;       // per path: origin of the pending ray / of the ray that produced the current hit; w = shadow-ray limit
+    PathField rayB;       // per path: direction; w = state bits
+    PathField hit;        // per path: t, leaf slot (bits), beta, gamma of the current vertex
     uint32_t* hitInst;    // per path: instance of the current vertex (scenes that are not a single mesh)
-    float4* thr;          // per path: throughput
+    PathField thr;        // per path: throughput
     float4* aux;          // per path: pending contribution (shadow ray) or the glossy vertex's hit point
     float4* result;       // per path
     // scenes with glass: normal used by the glass vertex (xyz) and the vertex's own t (w); the visibility
@@ -125,6 +136,7 @@ struct Batch {
     uint32_t tileSize, nRanks, rank, tilesX, nTiles;
     uint32_t sqrtM;       // (int)sqrt((double)material_aa): the stratification grid of a sample's first variance vertex
 };
+
 
 // Position `idx` of the call's pixel order -> pixel (x, y).  Returns the pixel's index in the frame buffer (the key
 // of its random numbers, so an image does not depend on how it was cut); `valid` is false for the padding of a square
@@ -334,7 +346,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         bool pvalid;
         it.pixel = tile_pixel(st, batch, batch.pixelStart + s0 / G, px, py, pvalid);
         if (!FIRST) {
-            // the vertex the pass will sample: the one after a vertex that waited for its own ray
+            // the vertex the pass will sample: the one after a vertex that waited for its own ray.  (This read also brings
+            // the path's block into the cache before the regrouped lanes ask for it: carrying the vertex in the queue
+            // entry instead, which saves the dependent read, measured no faster.)
             const uint32_t st0 = __float_as_uint(pool.rayB[it.p].w);
             vertexGuess = (st0 & ST_K_MASK) + ((st0 & (ST_GLOSSY_PENDING | ST_GLASS_PENDING | ST_RETRACE)) != 0u ? 1u : 0u);
         }
@@ -506,17 +520,17 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
 
         if (!done) {
             // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
-            // Everything the vertex needs from the scene is asked for here, side by side: the material index of the triangle,
-            // the instance record and the vertex normals.  (Fetched where they are first used, behind the branches on the
+            // Everything the vertex needs from the scene is asked for here, side by side: the triangle's shading record
+            // (vertex normals and material index) and the instance record.  (Fetched where they are first used, behind the branches on the
             // material type, they queue up one behind the other, and with four waves per SIMD that wait is what the pass
             // spends its time on.)  In a one-mesh scene the instance record is the same for every lane and comes through
             // the scalar cache.
             const DevInstance& in = sv.inst[sv.singleMesh ? 0u : inst];
             const uint32_t slot = __float_as_uint(hc.y);
             const float beta = hc.z, gamma = hc.w;
-            uint32_t tm = kInvalid;
-            if (sv.triMaterial) tm = sv.triMaterial[slot != kInvalid ? slot : 0u];   // uniform branch
-            F3 normal = sv.singleMesh ? hit_normal(sv, sv.inst[0], o, d, t, slot, beta, gamma) : hit_normal(sv, in, o, d, t, slot, beta, gamma);
+            const ShadeRec rec = load_shade_rec(sv, slot);
+            const uint32_t tm = rec.material();
+            F3 normal = sv.singleMesh ? hit_normal(sv.inst[0], o, d, t, slot, beta, gamma, rec) : hit_normal(in, o, d, t, slot, beta, gamma, rec);
             uint32_t mi = in.material;
             if (slot != kInvalid && tm != kInvalid) mi = tm;
             // PhotonMapMode::full: once `pmDepth` earlier vertices were diffuse, a diffuse closure reads the map
@@ -833,7 +847,12 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
             pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
             if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
-            if (writeAux) pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
+            // a path that ends with its shadow ray has no use for its throughput any more: what the ray is worth when it
+            // gets through waits in that record, inside the path's block, instead of in a cache line of its own
+            if (writeAux) {
+                if (pushShadow && !pushExt && !pushPhoton) pool.thr[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
+                else pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
+            }
             if ((RICH && sv.hasAdd) && pushExt) {
                 if (writeAcc) pool.acc[p] = f4(acc.r, acc.g, acc.b, 0.0f);
                 if (writePend) pool.accPend[p] = f4(pend.r, pend.g, pend.b, 0.0f);
@@ -874,7 +893,7 @@ __device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& po
     if (sticky) {
         if (occluded) pool.glassB[p] = f4(rb.x, rb.y, rb.z, __uint_as_float(kInvalid));
     } else if (!occluded) {
-        pool.result[p] = pool.aux[p];
+        pool.result[p] = pool.thr[p];   // the pending contribution (see shade_kernel)
     }
 }
 
@@ -956,7 +975,7 @@ __global__ __launch_bounds__(64) void trace_stage_count_kernel(SceneView sv, Poo
             if (sticky) {
                 if (occluded) pool.glassB[p] = f4(rb.x, rb.y, rb.z, __uint_as_float(kInvalid));
             } else if (!occluded) {
-                pool.result[p] = pool.aux[p];
+                pool.result[p] = pool.thr[p];   // the pending contribution (see shade_kernel)
             }
         }
         wave_add64(work + 3, has ? 1u : 0u, lane);
@@ -1119,9 +1138,16 @@ size_t pool_carve(Pool& pool, char* base, const PoolDims& d)
         return p;
     };
     const size_t P = (size_t)d.P, S = (size_t)d.S;
-    pool.rayA = (float4*)take(P * 16); pool.rayB = (float4*)take(P * 16); pool.hit = (float4*)take(P * 16);
+#ifdef RT_POOL_SOA
+    pool.rayA.base = (float4*)take(P * 16); pool.rayB.base = (float4*)take(P * 16); pool.hit.base = (float4*)take(P * 16);
+    pool.thr.base = (float4*)take(P * 16);
+#else
+    float4* const blocks = (float4*)take(P * 64);
+    pool.rayA.base = blocks; pool.rayB.base = blocks ? blocks + 1 : nullptr; pool.hit.base = blocks ? blocks + 2 : nullptr;
+    pool.thr.base = blocks ? blocks + 3 : nullptr;
+#endif
     pool.hitInst = (uint32_t*)take(d.single ? 4 : P * 4);
-    pool.thr = (float4*)take(P * 16); pool.aux = (float4*)take(P * 16); pool.result = (float4*)take(P * 16);
+    pool.aux = (float4*)take(P * 16); pool.result = (float4*)take(P * 16);
     pool.glassN = (float4*)take(d.glass ? P * 16 : 16); pool.glassA = (float4*)take(d.glass ? P * 16 : 16); pool.glassB = (float4*)take(d.glass ? P * 16 : 16);
     pool.acc = (float4*)take(d.add ? P * 16 : 16); pool.accPend = (float4*)take(d.add ? P * 16 : 16);
     pool.sA = (float4*)take(S * 16); pool.sB = (float4*)take(S * 16); pool.sC = (float4*)take(S * 16);

@@ -189,12 +189,10 @@ __global__ __launch_bounds__(64) void photon_trace_kernel(SceneView sv, const Em
         if (hr.inst == kInvalid) { alive = false; continue; }
         const DevInstance& in = sv.inst[hr.inst];
         uint32_t mi = in.material;
-        if (hr.slot != kInvalid && sv.triMaterial) {
-            const uint32_t tm = sv.triMaterial[hr.slot];
-            if (tm != kInvalid) mi = tm;
-        }
+        const ShadeRec rec = load_shade_rec(sv, hr.slot);
+        if (hr.slot != kInvalid && rec.material() != kInvalid) mi = rec.material();
         const F3 hitpoint = o + (d * hr.t);
-        const F3 normal = hit_normal(sv, in, o, d, hr.t, hr.slot, hr.beta, hr.gamma);
+        const F3 normal = hit_normal(in, o, d, hr.t, hr.slot, hr.beta, hr.gamma, rec);
         F3 newDir;
         RGBf newEnergy;
         float diffuseness;

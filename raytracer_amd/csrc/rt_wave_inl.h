@@ -63,16 +63,32 @@ __device__ __forceinline__ bool wave_any(const SceneView& sv, bool has, F3 o, F3
     }
 }
 
+// What the shade stage needs of the triangle at a leaf slot: vertex normals and material id (SceneView::shadeRecs).
+struct ShadeRec {
+    float4 q0, q1, q2;
+    __device__ __forceinline__ uint32_t material() const { return __float_as_uint(q2.y); }
+};
+// slot == kInvalid (a sphere, a miss): nothing is read, the material id is kInvalid
+__device__ __forceinline__ ShadeRec load_shade_rec(const SceneView& sv, uint32_t slot)
+{
+    ShadeRec r;
+    r.q0 = r.q1 = r.q2 = make_float4(0.0f, __uint_as_float(kInvalid), 0.0f, 0.0f);
+    if (slot != kInvalid) {
+        const float4* p = sv.shadeRecs + (size_t)slot * 3;
+        r.q0 = p[0]; r.q1 = p[1]; r.q2 = p[2];
+    }
+    return r;
+}
+
 // World-space shading normal of a hit: interpolated vertex normals (shape/TriangleMesh.cpp:114-120)
 // or the sphere's object-space hit point (shape/Sphere.cpp:52-53), then transformNormal + normalize
-// (shape/list/InstancedModelList.cpp:129-130, math/Transformation.h:95-99).
-__device__ __forceinline__ F3 hit_normal(const SceneView& sv, const DevInstance& in, F3 wo, F3 wd, float t, uint32_t slot, float beta, float gamma)
+// (shape/list/InstancedModelList.cpp:129-130, math/Transformation.h:95-99).  `rec` is the record of `slot` (unused for spheres).
+__device__ __forceinline__ F3 hit_normal(const DevInstance& in, F3 wo, F3 wd, float t, uint32_t slot, float beta, float gamma, const ShadeRec& rec)
 {
     F3 objN;
     if (slot != kInvalid) {
-        const float* vn = sv.vertNormals + (size_t)slot * 9;
         const float alfa = 1.0f - beta - gamma;
-        const F3 na = f3(vn[0], vn[1], vn[2]), nb = f3(vn[3], vn[4], vn[5]), nc = f3(vn[6], vn[7], vn[8]);
+        const F3 na = f3(rec.q0.x, rec.q0.y, rec.q0.z), nb = f3(rec.q0.w, rec.q1.x, rec.q1.y), nc = f3(rec.q1.z, rec.q1.w, rec.q2.x);
         objN = ((alfa * na) + (beta * nb)) + (gamma * nc);
     } else {
         const F3 oo = xf_point_inv(in.inv, wo), od = xf_vector_inv(in.inv, wd);
