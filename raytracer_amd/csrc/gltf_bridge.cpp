@@ -678,11 +678,19 @@ struct Loader {
         if (attrs->has("NORMAL")) load_floats(item("accessors", attrs->get_int("NORMAL", -1)), 3, m->normals);
         else throw Unsupported("Implicit normals are not supported");
         if (attrs->has("TEXCOORD_0")) load_floats(item("accessors", attrs->get_int("TEXCOORD_0", -1)), 2, m->texcoords);
-        const size_t nv = m->vertices.size() / 3;
-        if (m->normals.size() / 3 < nv) throw std::runtime_error("glTF: fewer normals than vertices");
-        if (!m->texcoords.empty() && m->texcoords.size() / 2 < nv) throw std::runtime_error("glTF: fewer texture coordinates than vertices");
-        for (uint32_t i : m->indices)
+        // The walks above run to the end of their buffer views, whatever the accessors' counts say, so accessors that
+        // share a view (positions followed by normals, say) give arrays of different lengths; the reference hands them to
+        // TriangleMesh as they are and one index triple addresses all three (:246-254).  Here every index must be inside
+        // every array (the reference would read past its vectors), and the arrays are then brought to one length -- the
+        // entries added or dropped are ones no triangle names.
+        const size_t nv = m->vertices.size() / 3, nn = m->normals.size() / 3, nt = m->texcoords.size() / 2;
+        for (uint32_t i : m->indices) {
             if (i >= nv) throw std::runtime_error("glTF: vertex index out of range");
+            if (i >= nn) throw std::runtime_error("glTF: normal index out of range");
+            if (!m->texcoords.empty() && i >= nt) throw std::runtime_error("glTF: texture coordinate index out of range");
+        }
+        m->normals.resize(nv * 3, 0.0f);
+        if (!m->texcoords.empty()) m->texcoords.resize(nv * 2, 0.0f);
         return m;
     }
 

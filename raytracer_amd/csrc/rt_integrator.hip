@@ -853,6 +853,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                 if (pushShadow && !pushExt && !pushPhoton) pool.thr[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
                 else pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
             }
+            // the first pass writes whole blocks (neighbouring lanes, neighbouring blocks): the hit record too, so that no
+            // cache line leaves the pass partly written
+            if (FIRST) pool.hit[p] = f4(0.0f, 0.0f, 0.0f, 0.0f);
             if ((RICH && sv.hasAdd) && pushExt) {
                 if (writeAcc) pool.acc[p] = f4(acc.r, acc.g, acc.b, 0.0f);
                 if (writePend) pool.accPend[p] = f4(pend.r, pend.g, pend.b, 0.0f);

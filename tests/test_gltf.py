@@ -666,3 +666,82 @@ def test_loader_under_address_and_undefined_behaviour_sanitizers(tmp_path):
     assert run.returncode == 0, (run.stdout + run.stderr)[-3000:]
     ok, err = [int(x) for x in run.stdout.split()[1::2]]
     assert ok > 100 and err > 100
+
+
+# ---- files not written by this repository's GlbBuilder ------------------------------------------------------
+# The JSON and the base64 buffers below are the published Khronos glTF tutorial samples "a minimal glTF file"
+# (gltfTutorial_003: one indexed triangle, positions only) and "simple meshes" (gltfTutorial_008: the same triangle
+# with normals, used by two nodes, the second translated by (1, 0, 0)), typed in from the tutorial; the .glb container
+# is assembled here byte by byte from the glTF 2.0 specification (12-byte header, JSON chunk padded with spaces, BIN
+# chunk padded with zeros), not by GlbBuilder.
+_KHRONOS_MINIMAL = """{
+  "scene": 0, "scenes": [{"nodes": [0]}], "nodes": [{"mesh": 0}],
+  "meshes": [{"primitives": [{"attributes": {"POSITION": 1}, "indices": 0}]}],
+  "buffers": [{"byteLength": 44}],
+  "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 6, "target": 34963},
+                  {"buffer": 0, "byteOffset": 8, "byteLength": 36, "target": 34962}],
+  "accessors": [{"bufferView": 0, "byteOffset": 0, "componentType": 5123, "count": 3, "type": "SCALAR", "max": [2], "min": [0]},
+                {"bufferView": 1, "byteOffset": 0, "componentType": 5126, "count": 3, "type": "VEC3", "max": [1.0, 1.0, 0.0], "min": [0.0, 0.0, 0.0]}],
+  "asset": {"version": "2.0"}
+}"""
+_KHRONOS_MINIMAL_BIN = "AAABAAIAAAAAAAAAAAAAAAAAAAAAAIA/AAAAAAAAAAAAAAAAAACAPwAAAAA="
+_KHRONOS_SIMPLE_MESHES = """{
+  "scene": 0, "scenes": [{"nodes": [0, 1]}],
+  "nodes": [{"mesh": 0}, {"mesh": 0, "translation": [1.0, 0.0, 0.0]}],
+  "meshes": [{"primitives": [{"attributes": {"POSITION": 1, "NORMAL": 2}, "indices": 0}]}],
+  "buffers": [{"byteLength": 80}],
+  "bufferViews": [{"buffer": 0, "byteOffset": 0, "byteLength": 6, "target": 34963},
+                  {"buffer": 0, "byteOffset": 8, "byteLength": 72, "byteStride": 12, "target": 34962}],
+  "accessors": [{"bufferView": 0, "byteOffset": 0, "componentType": 5123, "count": 3, "type": "SCALAR", "max": [2], "min": [0]},
+                {"bufferView": 1, "byteOffset": 0, "componentType": 5126, "count": 3, "type": "VEC3", "max": [1.0, 1.0, 0.0], "min": [0.0, 0.0, 0.0]},
+                {"bufferView": 1, "byteOffset": 36, "componentType": 5126, "count": 3, "type": "VEC3", "max": [0.0, 0.0, 1.0], "min": [0.0, 0.0, 1.0]}],
+  "asset": {"version": "2.0"}
+}"""
+_KHRONOS_SIMPLE_MESHES_BIN = ("AAABAAIAAAAAAAAAAAAAAAAAAAAAAIA/AAAAAAAAAAAAAAAAAACAPwAAAAAAAAAAAAAAAAAAgD8AAAAAAAAAAAAAgD8AAAAAAAAAAAAAgD8=")
+
+
+def _glb_by_hand(json_text, bin_b64, path):
+    import base64
+    js = json_text.encode("utf-8")
+    js += b" " * (-len(js) % 4)
+    blob = base64.b64decode(bin_b64)
+    blob += b"\0" * (-len(blob) % 4)
+    total = 12 + 8 + len(js) + 8 + len(blob)
+    with open(path, "wb") as f:
+        f.write(struct.pack("<4sII", b"glTF", 2, total))
+        f.write(struct.pack("<I4s", len(js), b"JSON") + js)
+        f.write(struct.pack("<I4s", len(blob), b"BIN\0") + blob)
+    return path
+
+
+def test_khronos_tutorial_files_assembled_by_hand(tmp_path):
+    """Independent inputs for the bridge.  The minimal triangle has no normals: loadGLTFScene refuses it with
+    "Implicit normals are not supported" (io/GLTF.cpp:229-238).  The simple-meshes file -- whose accessors share a buffer
+    view, which files written by GlbBuilder never do -- loads: one mesh stored once
+    (meshCache, :203-216), two instances (one per node and primitive, DynamicScene.cpp:99-161), the second moved by
+    (1, 0, 0); no camera ("No camera in scene.", renderer/Renderer.cpp:318), default material (white diffuse)."""
+    p = str(tmp_path)
+    with pytest.raises(api.RtgpuError, match="Implicit normals are not supported"):
+        gltf.load_glb(_glb_by_hand(_KHRONOS_MINIMAL, _KHRONOS_MINIMAL_BIN, os.path.join(p, "minimal.glb")))
+    with gltf.load_glb(_glb_by_hand(_KHRONOS_SIMPLE_MESHES, _KHRONOS_SIMPLE_MESHES_BIN, os.path.join(p, "simple.glb"))) as g:
+        sc = g.scene_data()
+        assert g.camera_count() == 0
+        with pytest.raises(api.RtgpuError, match="No camera in scene."):
+            g.camera()
+    assert len(sc.meshes) == 1 and len(sc.instances) == 2 and [i.shape for i in sc.instances] == [0, 0]
+    m = sc.meshes[0]
+    # positions and normals share one buffer view: loadVec3s walks from the accessor's start to the end of the *view*
+    # whatever the accessor's count says (io/GLTF.cpp:94-109), so the reference reads six "positions" (the three normals
+    # after the three positions) and three normals; the triangle only names vertices 0..2 of either array
+    assert np.array_equal(m.vertices, np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [0, 0, 1], [0, 0, 1]], np.float32))
+    assert np.array_equal(m.normals[:3], np.array([[0, 0, 1]] * 3, np.float32)) and len(m.normals) == 6
+    assert np.array_equal(np.asarray(m.indices).reshape(-1), [0, 1, 2])
+    assert np.array_equal(sc.instances[0].transform, np.eye(4)) and np.array_equal(sc.instances[1].transform, scenes.translate(1.0, 0.0, 0.0))
+    assert np.array_equal(sc.instances[1].inverse, scenes.translate(-1.0, 0.0, 0.0))
+    assert len(sc.point_lights) == 0 and len(sc.area_lights) == 0
+    # the oracle traces the loaded scene: a ray down -z above each triangle's inside hits instance 0 / 1 at t = 1
+    S = oracle.OracleScene(sc)
+    o = np.array([[0.25, 0.25, 1.0], [1.25, 0.25, 1.0], [0.9, 0.9, 1.0]], np.float32)
+    d = np.tile(np.array([[0.0, 0.0, -1.0]], np.float32), (3, 1))
+    h = S.trace_closest(o, d)
+    assert list(h["inst"]) == [0, 1, abi.INVALID_ID] and list(h["t"][:2]) == [1.0, 1.0] and list(h["prim"][:2]) == [0, 0]
