@@ -387,4 +387,85 @@ std::vector<Node128> collapse_tree4(const std::vector<Node64>& binary, uint32_t&
     return out;
 }
 
+namespace {
+
+// One node.  Per axis: origin = the smallest low plane of the node's children, step = a little more than 1/255 of the
+// extent, low planes rounded down and high planes rounded up on that grid.  The kernels decode a plane as
+// fma(q, step, origin - ray origin): against the exact (plane - ray origin) that differs by the rounding of
+// (origin - ray origin) instead of (plane - ray origin), at most 2^-24 of the node's extent more, so every plane off
+// the grid's ends is moved out by 2^-22 of the extent before it is rounded (the grid's ends decode exactly).  An axis on
+// which some child box is not finite gets a grid that spans all finite numbers: the child is entered whatever the ray.
+NodeQ64 quantize_node(const Node128& n)
+{
+    NodeQ64 q{};
+    uint8_t plane[4][6];
+    float step[3];
+    for (int a = 0; a < 3; ++a) {
+        double lo = DBL_MAX, hi = -DBL_MAX;
+        bool finite = true;
+        for (int k = 0; k < 4; ++k) {
+            if (n.c[k] == kEmptyChild) continue;
+            const double l = n.box[k][2 * a], h = n.box[k][2 * a + 1];
+            if (!std::isfinite(l) || !std::isfinite(h) || l > h) finite = false;
+            lo = std::min(lo, l);
+            hi = std::max(hi, h);
+        }
+        if (!finite || !(hi - lo < 1e37)) {
+            q.origin[a] = -1.5e38f;
+            step[a] = 1.2e36f;   // 255 steps = 3.06e38
+            for (int k = 0; k < 4; ++k) { plane[k][2 * a] = 0; plane[k][2 * a + 1] = 255; }
+            continue;
+        }
+        const float origin = (float)lo;   // exact: a child's plane
+        const double extent = hi - lo;
+        float st = (float)(extent / 255.0 * (1.0 + 1e-6));
+        while ((double)st * 255.0 < extent * (1.0 + 5e-7)) st = std::nextafter(st, FLT_MAX);
+        const double margin = std::ldexp(extent, -22);
+        q.origin[a] = origin;
+        step[a] = st;
+        for (int k = 0; k < 4; ++k) {
+            if (n.c[k] == kEmptyChild) { plane[k][2 * a] = 255; plane[k][2 * a + 1] = 0; continue; }
+            const double l = n.box[k][2 * a], h = n.box[k][2 * a + 1];
+            int ql = 0, qh = 255;
+            if (st > 0.0f) {
+                ql = (int)std::floor((l - margin - lo) / st);
+                qh = (int)std::ceil((h + margin - lo) / st);
+                ql = std::min(std::max(ql, 0), 255);
+                qh = std::min(std::max(qh, 0), 255);
+                while (ql > 0 && lo + (double)ql * st > l - margin) --ql;
+                while (qh < 255 && lo + (double)qh * st < h + margin) ++qh;
+            } else {
+                qh = 0;   // a flat node: every plane is the origin
+            }
+            plane[k][2 * a] = (uint8_t)ql;
+            plane[k][2 * a + 1] = (uint8_t)qh;
+        }
+    }
+    q.sx = step[0]; q.sy = step[1]; q.sz = step[2];
+    auto word = [&](int a, int k0) {
+        return (uint32_t)plane[k0][2 * a] | ((uint32_t)plane[k0][2 * a + 1] << 8) | ((uint32_t)plane[k0 + 1][2 * a] << 16) | ((uint32_t)plane[k0 + 1][2 * a + 1] << 24);
+    };
+    q.x01 = word(0, 0); q.x23 = word(0, 2);
+    q.y01 = word(1, 0); q.y23 = word(1, 2);
+    q.z01 = word(2, 0); q.z23 = word(2, 2);
+    for (int k = 0; k < 4; ++k) q.c[k] = n.c[k];
+    return q;
+}
+
+} // namespace
+
+std::vector<NodeQ64> quantize_tree4(const std::vector<Node128>& nodes, int threads)
+{
+    std::vector<NodeQ64> out(nodes.size());
+    const size_t n = nodes.size();
+    const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)std::max(threads, 1), n / 65536 + 1));
+    std::vector<std::thread> pool;
+    for (int t = 0; t < T; ++t)
+        pool.emplace_back([&, t]() {
+            for (size_t i = n * (size_t)t / (size_t)T, e = n * (size_t)(t + 1) / (size_t)T; i < e; ++i) out[i] = quantize_node(nodes[i]);
+        });
+    for (std::thread& th : pool) th.join();
+    return out;
+}
+
 } // namespace rt

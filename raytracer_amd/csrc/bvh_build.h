@@ -41,4 +41,8 @@ BuiltTree build_tree(const PrimBox* boxes, uint32_t n, const BuildParams& params
 // depth4 receives the number of four-way inner nodes on the longest root-to-leaf path (= ceil(binary depth / 2)).
 std::vector<Node128> collapse_tree4(const std::vector<Node64>& binary, uint32_t& depth4);
 
+// The quantised form the kernels fetch (see NodeQ64): every decoded child box contains the exact one, with room for the
+// rounding of the kernels' decode arithmetic.
+std::vector<NodeQ64> quantize_tree4(const std::vector<Node128>& nodes, int threads);
+
 } // namespace rt

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const f
 
 // Single-mesh scenes: wave-cooperative traversal with work stealing (rt_steal_inl.h).
 template <bool COUNT>
-__global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, const float* __restrict__ ro,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void trace_closest_steal_kernel(SceneView sv, const float* __restrict__ ro,
                                                                  const float* __restrict__ rd, uint64_t n, uint64_t nb8,
                                                                  rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
 {
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(64) void trace_closest_steal_kernel(SceneView sv, c
     }
 }
 
-__global__ __launch_bounds__(64) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
                                                              const float* __restrict__ rd, const float* __restrict__ tmax,
                                                              uint64_t n, uint64_t nb8, uint8_t* __restrict__ occ)
 {

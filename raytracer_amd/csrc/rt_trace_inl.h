@@ -191,21 +191,60 @@ __device__ __forceinline__ void xf_ray_inv(const double* m, bool identity, F3 wo
 // checks that both arrays are smaller than 4 GiB.
 __device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t node)
 {
+#if RT_NODE_Q8
+    return (const float4*)((const char*)sv.nodes + (node << 6));
+#else
     return (const float4*)((const char*)sv.nodes + (node << 7));
+#endif
 }
 
 // One step at an inner node of a four-way tree (Node128): the boxes of its children against the ray, and the children that
 // are hit ordered by entry distance.  c[0 .. n-1] = their references, nearest first; returns n.  `tested` = boxes tested
 // (the node's real children).  Child boxes only prune (see slab_fast), so the order is a heuristic, not part of the result.
+#if RT_NODE_Q8
+// The slab test on a child box given by its quantised planes (NodeQ64): plane = q * step + (grid origin - ray origin), one
+// packed fma per axis for both planes, then slab_fast's arithmetic.  (lo, hi) = bytes `shift` and `shift + 8` of the words.
+__device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_t wz, int shift, Pair stepX, Pair stepY, Pair stepZ,
+                                               Pair cx, Pair cy, Pair cz, Pair invX, Pair invY, Pair invZ, float tlimit, float& t0)
+{
+    const Pair qx = {(float)((wx >> shift) & 0xFFu), (float)((wx >> (shift + 8)) & 0xFFu)};
+    const Pair qy = {(float)((wy >> shift) & 0xFFu), (float)((wy >> (shift + 8)) & 0xFFu)};
+    const Pair qz = {(float)((wz >> shift) & 0xFFu), (float)((wz >> (shift + 8)) & 0xFFu)};
+    const Pair tx = __builtin_elementwise_fma(qx, stepX, cx) * invX;
+    const Pair ty = __builtin_elementwise_fma(qy, stepY, cy) * invY;
+    const Pair tz = __builtin_elementwise_fma(qz, stepZ, cz) * invZ;
+    const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
+    const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
+    t0 = tnear;
+    return tnear <= tfar;
+}
+#endif
+
 __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float tlim, int c[4], uint32_t& tested)
 {
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
     float t0, t1, t2, t3;
+#if RT_NODE_Q8
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q6 = np[3];
+    int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
+    const float ox = q0.x - o.x, oy = q0.y - o.y, oz = q0.z - o.z;
+    const Pair cx = {ox, ox}, cy = {oy, oy}, cz = {oz, oz};
+    const Pair sx = {q0.w, q0.w}, sy = {q1.x, q1.x}, sz = {q1.y, q1.y};
+    const float ivx = inv.x, ivy = inv.y, ivz = inv.z;   // (as scalars: a pair taken from two fields of the struct goes through private memory)
+    const Pair ix = {ivx, ivx}, iy = {ivy, ivy}, iz = {ivz, ivz};
+    const uint32_t x01 = __float_as_uint(q1.z), x23 = __float_as_uint(q1.w);
+    const uint32_t y01 = __float_as_uint(q2.x), y23 = __float_as_uint(q2.y), z01 = __float_as_uint(q2.z), z23 = __float_as_uint(q2.w);
+    const bool h0 = slab_quantised(x01, y01, z01, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t0);                      // the first child always exists
+    const bool h1 = slab_quantised(x01, y01, z01, 16, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t1) && c1 != kEmptyChild;
+    const bool h2 = slab_quantised(x23, y23, z23, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t2) && c2 != kEmptyChild;
+    const bool h3 = slab_quantised(x23, y23, z23, 16, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t3) && c3 != kEmptyChild;
+#else
+    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
     int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
     const bool h0 = slab_pairs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0);                      // the first child always exists
     const bool h1 = slab_pairs(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t1) && c1 != kEmptyChild;
     const bool h2 = slab_pairs(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, o, inv, tlim, t2) && c2 != kEmptyChild;
     const bool h3 = slab_pairs(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
+#endif
     tested = 1u + (c1 != kEmptyChild ? 1u : 0u) + (c2 != kEmptyChild ? 1u : 0u) + (c3 != kEmptyChild ? 1u : 0u);
     t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
     // children that are not hit sort behind the others: a five-exchange network on (entry distance, reference)

@@ -57,6 +57,24 @@ struct Node128 {
 };
 static_assert(sizeof(Node128) == 128, "Node128 must be two 64-byte blocks");
 
+// What the kernels fetch: the same four-way node with its child boxes quantised to 8 bits per plane on a grid laid over the
+// node's own box (origin = the box's low corner, one step = 1/255 of its extent per axis, rounded outwards, so a decoded
+// child box always contains the exact one).  One 64-byte line, four dwordx4 loads instead of seven: the traversal kernels
+// keep a compute unit's vector-memory path busy 75-90 % of the time, and the tree takes half the cache.
+// Plane words: byte 0 / 1 = low / high plane of the first child of the pair, byte 2 / 3 = of the second.
+#ifndef RT_NODE_Q8
+#define RT_NODE_Q8 1
+#endif
+struct NodeQ64 {
+    float origin[3];
+    float sx;            // grid step per axis
+    float sy, sz;
+    uint32_t x01, x23;   // x planes of children 0, 1 / 2, 3
+    uint32_t y01, y23, z01, z23;
+    int32_t c[4];        // as Node128::c
+};
+static_assert(sizeof(NodeQ64) == 64, "NodeQ64 must be one 64-byte block");
+
 inline int32_t encode_leaf(uint32_t first, uint32_t count) { return ~(int32_t)((first << 4) | (count - 1)); }
 // top-level leaves (instances): up to 256 instances per leaf, first < 2^23
 constexpr uint32_t kMaxTopLeaf = 256;
