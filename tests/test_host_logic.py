@@ -6,6 +6,7 @@ import subprocess
 import sys
 
 import numpy as np
+import pytest
 
 from raytracer_amd import abi, distributed, scenes
 
@@ -106,3 +107,18 @@ def test_sharded_render_gather_gloo_world2(tmp_path):
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
     assert "GATHER_OK" in outs[0]
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_quantised_nodes_contain_the_exact_child_boxes(tmp_path, kind):
+    """The 64-byte nodes the kernels fetch (8-bit planes on the node's own grid): tests/native/check_quantised_nodes.cpp
+    builds a tree over 200 000 boxes (small boxes / flat boxes at large coordinates / some non-finite boxes), collapses and
+    quantises it with the library's own code and checks every decoded plane against the exact one."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_q")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I" + os.path.join(root, "raytracer_amd", "csrc"), "-I" + os.path.join(root, "include"),
+                    "-o", exe, os.path.join(root, "tests", "native", "check_quantised_nodes.cpp")], check=True)
+    r = subprocess.run([exe, "200000", str(kind + 1), str(kind)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
