@@ -765,7 +765,9 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         for (int k = 0; k < 12; ++k) same = same && inst[0].inv[k] == ident[k] && !std::signbit(inst[0].inv[k]);
         v.identityXf = same ? 1u : 0u;
     }
-    v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 1;
+    // a wave steals once 16 of its lanes are out of work: with the 64-byte nodes the kernels are bound by instruction issue and
+    // fewer, fuller stealing rounds pay (1 / 4 / 8 / 16: bounce rays 5078 / 5122 / 5072 / 5187 Mrays/s, any-hit 5331 / 5433 / 5437 / 5605)
+    v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 16;
     v.gatherBudget = std::getenv("RTGPU_GATHER_BUDGET") ? (uint32_t)std::strtoul(std::getenv("RTGPU_GATHER_BUDGET"), nullptr, 10) : 192u;
     v.skipBlackShadow = std::getenv("RTGPU_SKIP_BLACK_SHADOW") ? std::atoi(std::getenv("RTGPU_SKIP_BLACK_SHADOW")) : 1;
     v.shadeRegroup = std::getenv("RTGPU_SHADE_REGROUP") ? std::atoi(std::getenv("RTGPU_SHADE_REGROUP")) : 1;

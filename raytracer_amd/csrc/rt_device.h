@@ -56,7 +56,7 @@ struct DevDirectionalLight {
 
 // Everything the kernels need, passed by value as a kernel argument.
 struct SceneView {
-    const float4* nodes;        // Node128 records as 8 x float4 (four-way trees: mesh trees and the library's own top-level tree)
+    const float4* nodes;        // NodeQ64 records as 4 x float4 (four-way trees: mesh trees and the library's own top-level tree)
     const float4* refNodes;     // refTop: the reference-order top-level tree, binary Node64 records as 4 x float4
     const float4* tris;         // TriRec records as 3 x float4
     const uint32_t* triIds;     // leaf slot -> caller's triangle index (per mesh, offset by triBase)

@@ -181,7 +181,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 __builtin_amdgcn_sched_barrier(0);   // keeps the LDS read in front of the loads below
                 int c[4];
                 uint32_t tested;
-                const int nh = node4_hits(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                const int nh = node4_hits<!ANY>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
                 if (COUNT) wb += tested;
 #ifdef RT_DEV_STATS
                 dsNodeIt += 1.0f / (float)__popcll(wave_ballot(true));
@@ -453,7 +453,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
                 int c[4];
                 uint32_t tested;
-                const int nh = node4_hits(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                const int nh = node4_hits<!ANY>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
                 if (COUNT) wb += tested;
                 if (nh > 3) push(c[3]);
                 if (nh > 2) push(c[2]);

@@ -198,7 +198,7 @@ __device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t 
 #endif
 }
 
-// One step at an inner node of a four-way tree (Node128): the boxes of its children against the ray, and the children that
+// One step at an inner node of a four-way tree (NodeQ64; Node128 in a build with RT_NODE_Q8=0): the boxes of its children against the ray, and the children that
 // are hit ordered by entry distance.  c[0 .. n-1] = their references, nearest first; returns n.  `tested` = boxes tested
 // (the node's real children).  Child boxes only prune (see slab_fast), so the order is a heuristic, not part of the result.
 #if RT_NODE_Q8
@@ -220,6 +220,10 @@ __device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_
 }
 #endif
 
+// ORDERED = false (any-hit queries, where the first hit found ends the search and no child is nearer to the answer than
+// another): the children that are hit come first, in the node's own order -- the exchanges then move references only and
+// their conditions are mask arithmetic, about 20 vector instructions fewer per step.
+template <bool ORDERED = true>
 __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float tlim, int c[4], uint32_t& tested)
 {
     float t0, t1, t2, t3;
@@ -246,17 +250,30 @@ __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float 
     const bool h3 = slab_pairs(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
 #endif
     tested = 1u + (c1 != kEmptyChild ? 1u : 0u) + (c2 != kEmptyChild ? 1u : 0u) + (c3 != kEmptyChild ? 1u : 0u);
-    t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
-    // children that are not hit sort behind the others: a five-exchange network on (entry distance, reference)
+    const int nh = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+    if constexpr (ORDERED) {
+        t0 = h0 ? t0 : INFINITY; t1 = h1 ? t1 : INFINITY; t2 = h2 ? t2 : INFINITY; t3 = h3 ? t3 : INFINITY;
+        // children that are not hit sort behind the others: a five-exchange network on (entry distance, reference)
 #define RT_CSWAP(ta, ca, tb, cb) { const bool sw = tb < ta; const float tl = sw ? tb : ta, th = sw ? ta : tb; const int cl = sw ? cb : ca, ch = sw ? ca : cb; ta = tl; tb = th; ca = cl; cb = ch; }
-    RT_CSWAP(t0, c0, t1, c1)
-    RT_CSWAP(t2, c2, t3, c3)
-    RT_CSWAP(t0, c0, t2, c2)
-    RT_CSWAP(t1, c1, t3, c3)
-    RT_CSWAP(t1, c1, t2, c2)
+        RT_CSWAP(t0, c0, t1, c1)
+        RT_CSWAP(t2, c2, t3, c3)
+        RT_CSWAP(t0, c0, t2, c2)
+        RT_CSWAP(t1, c1, t3, c3)
+        RT_CSWAP(t1, c1, t2, c2)
 #undef RT_CSWAP
+    } else {
+        // the same network on (hit or not, reference)
+        bool g0 = h0, g1 = h1, g2 = h2, g3 = h3;
+#define RT_HSWAP(ga, ca, gb, cb) { const bool sw = gb && !ga; const int cl = sw ? cb : ca, ch = sw ? ca : cb; const bool gl = ga || gb, gh = ga && gb; ca = cl; cb = ch; ga = gl; gb = gh; }
+        RT_HSWAP(g0, c0, g1, c1)
+        RT_HSWAP(g2, c2, g3, c3)
+        RT_HSWAP(g0, c0, g2, c2)
+        RT_HSWAP(g1, c1, g3, c3)
+        RT_HSWAP(g1, c1, g2, c2)
+#undef RT_HSWAP
+    }
     c[0] = c0; c[1] = c1; c[2] = c2; c[3] = c3;
-    return (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
+    return nh;
 }
 __device__ __forceinline__ const float4* tri_ptr(const SceneView& sv, uint32_t slot)
 {

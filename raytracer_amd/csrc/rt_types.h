@@ -2,13 +2,14 @@
 //
 // HBM layout of a scene (all arrays hipMalloc'ed once per scene, read-only while tracing):
 //
-//   nodes  : Node128[] every tree (one per mesh + the top-level tree over instances)
-//            concatenated, each tree in depth-first order.  A Node128 is one INNER node of a four-way
+//   nodes  : NodeQ64[] every tree (one per mesh + the top-level tree over instances)
+//            concatenated, each tree in depth-first order.  A node is one INNER node of a four-way
 //            tree and carries the boxes of ALL its children (the reference also tests the child boxes at
-//            the parent, shape/bvh/BVHNode.h:316-320), so a traversal step is one 128-byte fetch
-//            (8 x dwordx4 from one aligned block).  Leaves have no record of their own:
-//            a child reference < 0 encodes (first primitive, count).  Node64 is the builder's binary
-//            form (and the form of the reference-order top-level tree of scenes with spheres).
+//            the parent, shape/bvh/BVHNode.h:316-320), quantised to 8 bits per plane on the node's own
+//            grid, so a traversal step is one 64-byte fetch (4 x dwordx4 from one aligned block).
+//            Leaves have no record of their own: a child reference < 0 encodes (first primitive, count).
+//            Node128 is the same node with fp32 boxes (the builder's intermediate form), Node64 the builder's
+//            binary form (and the form of the reference-order top-level tree of scenes with spheres).
 //   tris   : TriRec[]  48 bytes per triangle, in leaf order per mesh: vertex a, edges
 //            e1 = a-b, e2 = a-c (the same fp32 subtractions Triangle::intersect performs per
 //            test, math/Triangle.h:38-39) and the three cofactors of rows (e1,e2) shared by the
