@@ -61,6 +61,11 @@ def attach_counters(rl, c, src, per):
     the profile was taken from (its commit is in the summary file), the times beside them to this run."""
     rl["traffic"] = c.get("hbm_bytes_per_" + per)
     rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
+    if c.get("valu_issue_frac"):
+        # what the counters show binding: the kernels issue VALU instructions in most of the issue slots there are
+        rl["binding"] = {"resource": "valu_issue", "frac": c["valu_issue_frac"], "waiting_share_of_wave_cycles": c.get("wait_any_share_of_wave_cycles"),
+                         "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time), counters and time of the profiled run",
+                         "source": "committed profile " + src + " (not measured in this run)"}
     if c.get("hbm_GBps"):
         rl["hbm"] = {"GBps": c["hbm_GBps"], "frac_of_peak": c["hbm_GBps"] / HBM_PEAK_GBS, "l2_hit_rate": c.get("l2_hit_rate"),
                      "note": "2 x FETCH_SIZE + WRITE_SIZE over the kernel's time; an upper bound for 16-byte gathers",
@@ -433,7 +438,8 @@ def main():
         if not args.no_roofline:
             rl, stages = frame_rooflines(torch, api, abi, res["handle"], res["cam"], st, dev, info, "trace_stage_kernel<kTraceSingle>")
             counters, src = committed_counters(args.profile_tag)
-            if counters and "headline_trace_stage" in counters:
+            default_frame = (args.width, args.height, args.gaa, args.maa, args.subdiv) == (3840, 2160, 8, 8, 8)   # the frame the profile was taken on
+            if counters and "headline_trace_stage" in counters and default_frame:
                 attach_counters(rl, counters["headline_trace_stage"], src, "frame")
             out["roofline"] = rl
             out["stages_one_batch_in_flight"] = stages

@@ -41,6 +41,9 @@ def test_bench_single_gpu_line():
     assert d["cpu_baseline"]["value"] > 0 and d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["gpu_tile_vs_oracle_rel_rmse"] < 1e-3
     ex = d["extras"]
     check_roofline(ex["configs[1]"]["primary"]["roofline"])
+    assert "counters" not in d["roofline"]   # a reduced frame does not quote the committed counters of the full one
+    b = ex["configs[1]"]["bounce"]["roofline"].get("binding")   # configs[1] is run at its full size: the committed counters apply
+    assert b is None or (b["resource"] == "valu_issue" and 0 < b["frac"] < 1 and "committed profile" in b["source"])
     check_roofline(ex["configs[1]"]["bounce"]["roofline"])
     check_roofline(ex["configs[2]"]["roofline"])
     assert ex["configs[2]"]["ms_per_frame"] > 0 and ex["configs[2]"]["rays_per_frame"] > 1e8
