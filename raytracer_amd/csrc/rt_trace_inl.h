@@ -203,7 +203,9 @@ __device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t 
 // (the node's real children).  Child boxes only prune (see slab_fast), so the order is a heuristic, not part of the result.
 #if RT_NODE_Q8
 // The slab test on a child box given by its quantised planes (NodeQ64): plane = q * step + (grid origin - ray origin), one
-// packed fma per axis for both planes, then slab_fast's arithmetic.  (lo, hi) = bytes `shift` and `shift + 8` of the words.
+// packed fma per axis for both planes, times 1/d.  The plane words arrive with the plane the ray meets first in the lower
+// byte of each pair (node4_hits swaps the bytes of an axis the ray runs down), so the entry and exit distances need no
+// min / max per axis.  (near, far) = bytes `shift` and `shift + 8` of the words.
 __device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_t wz, int shift, Pair stepX, Pair stepY, Pair stepZ,
                                                Pair cx, Pair cy, Pair cz, Pair invX, Pair invY, Pair invZ, float tlimit, float& t0)
 {
@@ -213,10 +215,17 @@ __device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_
     const Pair tx = __builtin_elementwise_fma(qx, stepX, cx) * invX;
     const Pair ty = __builtin_elementwise_fma(qy, stepY, cy) * invY;
     const Pair tz = __builtin_elementwise_fma(qz, stepZ, cz) * invZ;
-    const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
-    const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
+    // v_max3 / v_min3 drop a NaN operand (0 * inf: the ray lies in the plane and runs along it): that slab counts as passed
+    const float tnear = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
+    const float tfar = fminf(fminf(fminf(tx.y, ty.y), tz.y), tlimit);
     t0 = tnear;
     return tnear <= tfar;
+}
+// byte selector for v_perm_b32 that keeps (d >= 0) or swaps (d < 0) the two bytes of each pair of a plane word
+__device__ __forceinline__ uint32_t near_first(uint32_t word, float invd)
+{
+    const uint32_t sel = 0x03020100u ^ ((uint32_t)(__float_as_int(invd) >> 31) & 0x01010101u);
+    return __builtin_amdgcn_perm(word, word, sel);
 }
 #endif
 
@@ -235,8 +244,9 @@ __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float 
     const Pair sx = {q0.w, q0.w}, sy = {q1.x, q1.x}, sz = {q1.y, q1.y};
     const float ivx = inv.x, ivy = inv.y, ivz = inv.z;   // (as scalars: a pair taken from two fields of the struct goes through private memory)
     const Pair ix = {ivx, ivx}, iy = {ivy, ivy}, iz = {ivz, ivz};
-    const uint32_t x01 = __float_as_uint(q1.z), x23 = __float_as_uint(q1.w);
-    const uint32_t y01 = __float_as_uint(q2.x), y23 = __float_as_uint(q2.y), z01 = __float_as_uint(q2.z), z23 = __float_as_uint(q2.w);
+    const uint32_t x01 = near_first(__float_as_uint(q1.z), ivx), x23 = near_first(__float_as_uint(q1.w), ivx);
+    const uint32_t y01 = near_first(__float_as_uint(q2.x), ivy), y23 = near_first(__float_as_uint(q2.y), ivy);
+    const uint32_t z01 = near_first(__float_as_uint(q2.z), ivz), z23 = near_first(__float_as_uint(q2.w), ivz);
     const bool h0 = slab_quantised(x01, y01, z01, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t0);                      // the first child always exists
     const bool h1 = slab_quantised(x01, y01, z01, 16, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t1) && c1 != kEmptyChild;
     const bool h2 = slab_quantised(x23, y23, z23, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t2) && c2 != kEmptyChild;
