@@ -67,5 +67,5 @@ if "--no-frame" not in sys.argv:
     p = r.render_profile_device(scene, cam, st, fb)
     rays = s.extension_rays + s.shadow_rays
     res.append("frame %.1f ms trace %.1f ms (%.0f Mrays/s) shade %.1f ms" % (s.device_ms, p.trace_ms, rays / p.trace_ms / 1e3, p.shade_ms))
-    res.append("img %.6f" % float(fb[torch.isfinite(fb)].mean()))
+    res.append("img %.6f bits %d" % (float(fb[torch.isfinite(fb)].mean()), int(fb.view(torch.int32).to(torch.int64).sum().item() % 1000000007)))
 print(os.environ.get("RTGPU_LIB", "default"), "|", " | ".join(res), "| chk", chk)
