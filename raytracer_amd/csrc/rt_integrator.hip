@@ -1266,8 +1266,11 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
             launch(photon_gather_tail_kernel, std::min(bound, tailCap), 64, ls, sv, pool, (const uint32_t*)cnt);
             TE(kStageGather);
         }
-        // extension and shadow queue are each at most `bound` long
-        const uint32_t traceBlocks = 2 * ((bound + 63) / 64);
+        // A shaded path leaves at most one ray behind -- an extension ray or a shadow ray -- so both queues together are at
+        // most `bound` long (two block counts rounded up: + 2); only a glass vertex can leave both (its own ray and the
+        // look along the direction it did not take), then each queue can be `bound` long.  Surplus workgroups find
+        // nothing to do and leave, but their launches are not free.
+        const uint32_t traceBlocks = sv.hasGlass ? 2 * ((bound + 63) / 64) : (bound + 63) / 64 + 2;
         TB();
         if (ln.work) launch(trace_stage_count_kernel, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt, ln.work);
         else if (mode == kTraceSingle) launch(trace_stage_kernel<kTraceSingle>, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt);
