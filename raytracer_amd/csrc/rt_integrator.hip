@@ -329,6 +329,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     // FIRST: every path of the batch; later passes: the extension queue the previous pass filled, whose length is read
     // here (the grid is sized from an upper bound the host knows, surplus workgroups find nothing to do)
     const uint32_t nIn = FIRST ? nPaths : cntIn[0];
+    if (blockIdx.x * (uint32_t)kShadeBlock >= nIn) return;   // a surplus workgroup (the grid covers an upper bound of the queue): nothing to regroup or push
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
