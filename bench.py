@@ -434,16 +434,20 @@ def main():
                    "tree_nodes": int(info.n_nodes), "tree_max_depth": int(info.max_depth), "scene_build_ms": float(info.build_ms),
                    "scene_hbm_bytes": int(info.device_bytes), "gather": res["gather"], **res["checks"]},
     }
-    if rank == 0 and world == 1:
+    if rank == 0:
         if not args.no_roofline:
+            # (with several ranks: the whole frame once more on rank 0's GPU alone -- the kernels' roofline does not depend on
+            # how the frame is shared out; the other ranks wait at the final barrier meanwhile)
             rl, stages = frame_rooflines(torch, api, abi, res["handle"], res["cam"], st, dev, info, "trace_stage_kernel<kTraceSingle>")
+            if world > 1:
+                rl["measured"] += "; whole frame on rank 0's GPU alone"
             counters, src = committed_counters(args.profile_tag)
             default_frame = (args.width, args.height, args.gaa, args.maa, args.subdiv) == (3840, 2160, 8, 8, 8)   # the frame the profile was taken on
             if counters and "headline_trace_stage" in counters and default_frame:
                 attach_counters(rl, counters["headline_trace_stage"], src, "frame")
             out["roofline"] = rl
             out["stages_one_batch_in_flight"] = stages
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             try:
                 out["cpu_baseline"] = cpu_baseline(res, abi, api, torch, dev)
             except Exception as e:  # noqa: BLE001

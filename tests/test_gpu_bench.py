@@ -57,3 +57,5 @@ def test_bench_two_ranks_rehearsal_over_gloo():
     assert p.returncode == 0, (p.stdout + p.stderr)[-3000:]
     d = check_line(p.stdout, 2, 2)
     assert "cpu_baseline" not in d and "extras" not in d and "rehearsal" in d["config"]["gather"]
+    check_roofline(d["roofline"])   # rank 0 measures the kernels' roofline on the whole frame, whatever the number of ranks
+    assert "rank 0" in d["roofline"]["measured"]
