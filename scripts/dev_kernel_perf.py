@@ -66,6 +66,6 @@ if "--no-frame" not in sys.argv:
     s = r.render_device(scene, cam, st, fb)
     p = r.render_profile_device(scene, cam, st, fb)
     rays = s.extension_rays + s.shadow_rays
-    res.append("frame %.1f ms trace %.1f ms (%.0f Mrays/s) shade %.1f ms" % (s.device_ms, p.trace_ms, rays / p.trace_ms / 1e3, p.shade_ms))
+    res.append("frame %.1f ms trace %.1f ms (%.0f Mrays/s) shade %.1f ms primary %.2f ms resolve %.2f ms" % (s.device_ms, p.trace_ms, rays / p.trace_ms / 1e3, p.shade_ms, p.primary_ms, p.resolve_ms))
     res.append("img %.6f bits %d" % (float(fb[torch.isfinite(fb)].mean()), int(fb.view(torch.int32).to(torch.int64).sum().item() % 1000000007)))
 print(os.environ.get("RTGPU_LIB", "default"), "|", " | ".join(res), "| chk", chk)
