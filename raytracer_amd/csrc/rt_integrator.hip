@@ -68,6 +68,14 @@ constexpr uint32_t ST_PREV_ROUGH = 1u << 18;      // caustics mode: the previous
 
 constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
 
+#ifdef RT_SHADE_STATS
+// developer build: lanes and waves that reach marked places of the later shade passes (slot 2k = lanes, 2k + 1 = waves)
+__device__ unsigned long long g_shade_stats[64];
+#define SHADE_STAT(k, pred) do { if (!FIRST) { const unsigned long long m_ = __ballot(pred); if (m_ != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_shade_stats[2 * (k)], (unsigned long long)__popcll(m_)); atomicAdd(&g_shade_stats[2 * (k) + 1], 1ull); } } } while (0)
+#else
+#define SHADE_STAT(k, pred) do { } while (0)
+#endif
+
 // Path state lives in 16-byte records so that every access is one full-width load or store per
 // lane (paths are reached through queues, i.e. at scattered indices: 4-byte fields in separate
 // arrays would each cost a memory transaction of their own).
@@ -357,6 +365,8 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     if (sv.shadeRegroup) it = shade_regroup<kShadeBlock>(sv, st.seed, M, it, vertexGuess);   // uniform branch
     const bool active = it.active;
     const uint32_t p = it.p;
+    SHADE_STAT(0, true);
+    SHADE_STAT(1, active);
     if (active) {
         const int maxLen = st.max_path_length;
         const uint32_t s = p / M, j = it.j, i = it.i;
@@ -398,6 +408,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         if (!FIRST && (RICH && sv.hasAdd)) { const float4 aq = pool.acc[p]; acc = rgb(aq.x, aq.y, aq.z); }
 
         if (state & ST_GLOSSY_PENDING) {
+            SHADE_STAT(2, true);
             // GlossyMaterial::sampleTransport after its own traceRay (material/GlossyMaterial.cpp:126-178),
             // then the Russian roulette of samplePath for that vertex (renderer/Renderer.cpp:52)
             const bool rough = (state & ST_GLOSSY_ROUGH) != 0;
@@ -512,6 +523,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                 state = (state & ~ST_K_MASK) | (uint32_t)k;
             }
         } else if (k > 0 && !hit) {
+            SHADE_STAT(3, true);
             // the extension ray left the scene: the path ends at the previous vertex and collects
             // the environment along its transport direction (renderer/Renderer.cpp:73-76, 94-98)
             done = true;
@@ -520,6 +532,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         }
 
         if (!done) {
+            SHADE_STAT(4, true);
             // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
             // Everything the vertex needs from the scene is asked for here, side by side: the triangle's shading record
             // (vertex normals and material index) and the instance record.  (Fetched where they are first used, behind the branches on the
@@ -609,6 +622,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                 result = rgb_mul(thr, rgb_add(addE, rgb_scale_d(color, mat.intensity)));
             } else if (lastVertex) {
                 done = true;
+                SHADE_STAT(5, true);
             } else if (mat.type == RTGPU_MAT_TRANSPARENT) {
                 // TransparentMaterial (material/TransparentMaterial.cpp:3-16): straight on, bsdf = identity,
                 // Russian roulette 0.01 (renderer/Renderer.cpp:52, 104-107)
@@ -741,6 +755,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                     // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
                     const bool useNEE = rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5f;
                     if (useNEE) {
+                        SHADE_STAT(6, true);
                         const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
@@ -761,6 +776,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                         }
                     } else {
                         const Basis3 basis = basis_from(normal);
+                        SHADE_STAT(7, true);
                         float sx, sy;
                         stratified_square(sampleGrid, (float)sampleI,
                                           rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
@@ -799,6 +815,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                     const bool neeEnabled = roughness > 0;
                     const bool useNEE = neeEnabled && rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5;
                     if (useNEE) {
+                        SHADE_STAT(8, true);
                         const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
@@ -817,6 +834,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                             pushShadow = !(sv.skipBlackShadow && neeRadiance.r == 0.0f && neeRadiance.g == 0.0f && neeRadiance.b == 0.0f);
                         }
                     } else {
+                        SHADE_STAT(9, true);
                         float sx, sy;
                         stratified_square(sampleCount, (float)sampleI,
                                           rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
@@ -845,6 +863,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         }
         repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
         if (pushExt || pushShadow || pushPhoton) {
+            SHADE_STAT(10, true);
             pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
             pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
             if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
@@ -1410,9 +1429,28 @@ hipError_t ensure_lane(RenderCache::Lane& l, const PoolDims& dims, std::string& 
 
 } // namespace
 
+#ifdef RT_SHADE_STATS
+struct ShadeStatsPrinter {
+    ~ShadeStatsPrinter()
+    {
+        unsigned long long h[64];
+        if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_shade_stats), sizeof(h)) != hipSuccess) return;
+        static const char* names[] = {"entered", "active after regroup", "glossy pending", "miss after bounce", "vertex evaluated", "last vertex",
+                                      "diffuse nee", "diffuse bounce", "glossy nee", "glossy bounce", "state written"};
+        for (int k = 0; k < 11; ++k)
+            std::fprintf(stderr, "shade stat %-22s lanes %14llu waves %12llu lanes/wave %.1f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (double)h[2 * k + 1] : 0.0);
+        std::memset(h, 0, sizeof(h));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_stats), h, sizeof(h));
+    }
+};
+#endif
+
 hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, const TileOrder* order,
                             float* dOut, rtgpu_render_stats* stats, uint64_t* work, hipStream_t stream, std::string& err, rtgpu_render_profile* profile)
 {
+#ifdef RT_SHADE_STATS
+    ShadeStatsPrinter shadeStatsPrinter;
+#endif
     const SceneView& sv = scene.view;
     std::lock_guard<std::mutex> cacheLock(scene.cacheMutex);
     Batch proto;
