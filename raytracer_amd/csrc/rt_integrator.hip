@@ -1100,6 +1100,54 @@ __global__ __launch_bounds__(256) void resolve_kernel(Pool pool, rtgpu_render_se
     fb[3 * (size_t)pixel] = px.r; fb[3 * (size_t)pixel + 1] = px.g; fb[3 * (size_t)pixel + 2] = px.b;
 }
 
+// The same sums with M = 2, 4, 8 or 16 lanes per pixel: lane j of a pixel's group loads result j of a sample (the group's
+// loads are one run of M * 16 bytes instead of one 16-byte piece per lane and kilobyte), and the sample's sum is formed in
+// the same order -- ((r0 + r1) + r2) + ... -- by M - 1 additions whose second operand comes from the lane to the left
+// (DPP row shift): after step s lane j holds the left-to-right sum of results j - s .. j, so lane M - 1 ends with the sum
+// resolve_kernel forms.  Bit-identical pixels; one thread per pixel left the kernel waiting on its loads (96 % of its cycles).
+template <int M>
+__global__ __launch_bounds__(256) void resolve_lanes_kernel(Pool pool, rtgpu_render_settings st, Batch batch, float* __restrict__ fb)
+{
+    constexpr uint32_t kPerBlock = 256u / (uint32_t)M;
+    const uint32_t j = threadIdx.x % (uint32_t)M;
+    const uint32_t pl = blockIdx.x * kPerBlock + threadIdx.x / (uint32_t)M;
+    const bool has = pl < batch.nPixels;
+    const uint32_t plc = has ? pl : 0u;
+    const uint32_t G = (uint32_t)st.geometry_aa;
+    RGBf px = rgb(0, 0, 0);
+    for (uint32_t i = 0; i < G; ++i) {
+        const uint32_t s = plc * G + i;
+        const bool all = pool.sLive[s] && pool.sHasVar[s];
+        // (a sample without a variance vertex only has result 0: the other lanes read nothing)
+        float4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
+        if (has && (all || j == 0u)) v = pool.result[(size_t)s * M + j];
+        float ar = v.x, ag = v.y, ab = v.z;
+#pragma unroll
+        for (int step = 1; step < M; ++step) {
+            // row_shr:1 = 0x111; lanes without a left neighbour in their row get 0 (they are lane 0 of a group: not read)
+            ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111, 0xF, 0xF, true)) + v.x;
+            ag = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ag), 0x111, 0xF, 0xF, true)) + v.y;
+            ab = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ab), 0x111, 0xF, 0xF, true)) + v.z;
+        }
+        // lane M - 1 now holds ((r0 + r1) + ...) + r(M-1); a sample without variance is its result 0 alone, which lane 0 holds
+        RGBf m = rgb(ar, ag, ab);
+        if (all) m = rgb_scale_f(m, 1.0f / (float)M);
+        else {
+            // bring lane 0's value to lane M - 1 (M - 1 more shifts would do; one ds_bpermute is cheaper)
+            const int src = (int)(threadIdx.x & 63u) - (M - 1);
+            m.r = __shfl(v.x, src, 64); m.g = __shfl(v.y, src, 64); m.b = __shfl(v.z, src, 64);
+        }
+        px.r += m.r; px.g += m.g; px.b += m.b;
+    }
+    if (!has || j != (uint32_t)(M - 1)) return;
+    int x, y;
+    bool valid;
+    uint32_t pixel = tile_pixel(st, batch, batch.pixelStart + pl, x, y, valid);
+    if (batch.tileSize != 0u) pixel = batch.pixelStart + pl;   // compact buffer: the call's pixel order
+    px = rgb_scale_f(px, 1.0f / (float)G);
+    fb[3 * (size_t)pixel] = px.r; fb[3 * (size_t)pixel + 1] = px.g; fb[3 * (size_t)pixel + 2] = px.b;
+}
+
 // Primary rays of a batch traversed on their own, only to count their work: work[6..8] = rays, boxes, triangles.
 __global__ __launch_bounds__(64) void primary_count_kernel(SceneView sv, rtgpu_camera cam, rtgpu_render_settings st, Batch batch,
                                                            unsigned long long* __restrict__ work)
@@ -1301,7 +1349,15 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
         steps = step + 1;
     }
     TB();
-    launch(resolve_kernel, (batch.nPixels + 255) / 256, 256, ls, pool, st, batch, dOut);
+    const char* const resolveEnv = std::getenv("RTGPU_RESOLVE_LANES");   // 0: one thread per pixel for every M
+    const bool resolveLanes = !(resolveEnv && std::atoi(resolveEnv) == 0);
+    switch (resolveLanes ? M : 0u) {
+    case 2: launch(resolve_lanes_kernel<2>, (batch.nPixels + 127) / 128, 256, ls, pool, st, batch, dOut); break;
+    case 4: launch(resolve_lanes_kernel<4>, (batch.nPixels + 63) / 64, 256, ls, pool, st, batch, dOut); break;
+    case 8: launch(resolve_lanes_kernel<8>, (batch.nPixels + 31) / 32, 256, ls, pool, st, batch, dOut); break;
+    case 16: launch(resolve_lanes_kernel<16>, (batch.nPixels + 15) / 16, 256, ls, pool, st, batch, dOut); break;
+    default: launch(resolve_kernel, (batch.nPixels + 255) / 256, 256, ls, pool, st, batch, dOut); break;
+    }
     TE(kStageResolve);
     RB_TRY(hipGetLastError());
     if (ln.hostCounters && steps > 0) {

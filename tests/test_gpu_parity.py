@@ -406,6 +406,26 @@ def test_render_tile_and_batching_do_not_change_pixels():
         assert np.array_equal(again, full)  # run-to-run deterministic
 
 
+@pytest.mark.parametrize("M", [2, 3, 4, 8, 16])
+def test_pixel_sums_by_lane_groups_equal_the_sums_by_one_thread(M, monkeypatch):
+    """The resolve pass adds a pixel's results in the reference's order (renderer/Renderer.cpp:236-263).  For 2, 4, 8 and
+    16 material samples it does so with one lane per result (ordered additions over neighbouring lanes); the frame must be
+    the one the one-thread-per-pixel kernel gives (RTGPU_RESOLVE_LANES=0; other sample counts always take that kernel), on
+    scenes that have samples with and without a variance vertex: a box with a mirror ball (paths that only meet the mirror
+    and the light have none), and an open scene whose rays partly leave it (pixels without a hit)."""
+    W, H = 37, 29
+    for sc, cam_m, yfov in (scenes.box_scene(with_mirror=True), scenes.c1_scene(n_small=10)):
+        cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+        st = abi.make_settings(W, H, geometry_aa=3, material_aa=M, seed=5)
+        with api.Scene(sc) as g:
+            monkeypatch.delenv("RTGPU_RESOLVE_LANES", raising=False)
+            lanes, _ = api.Renderer().render(g, cam, st)
+            monkeypatch.setenv("RTGPU_RESOLVE_LANES", "0")
+            single, _ = api.Renderer().render(g, cam, st)
+        assert np.array_equal(lanes.view(np.uint32), single.view(np.uint32))
+        assert lanes.mean() > 0.001
+
+
 def test_sharded_frame_is_bit_identical_to_single_pass():
     """The multi-GPU decomposition on one GPU: the squares of rank 0..G-1 rendered one after the other into compact
     buffers (rtgpu_render_tiles_device) and written back by the gather's last step (rtgpu_scatter_tiles_device) give the
