@@ -14,11 +14,10 @@
 // Non-negative floats order like their bit patterns, so the atomic min keeps the smallest t and,
 // among equal t, the smallest triangle index -- exactly the tree-independent result definition of
 // trace_ray(), whatever the schedule.  The upper half is also every worker's pruning distance.
-// The winning triangle's leaf slot is written by the lane whose value is the minimum when it
-// re-reads the word after its atomic; a later, smaller hit overwrites it in program order.  The
-// barycentric coordinates are not kept per candidate: hit_barycentrics() repeats the winning
-// test (same operands, same result bits) once per ray after the traversal, which keeps the LDS
-// block at 4.5 KB.
+// The winning triangle's leaf slot and barycentric coordinates are written by the lane whose value
+// is the minimum when it re-reads the word after its atomic (exactly one lane per ray and step:
+// the atomics of a step have all been served by then); a later, smaller hit overwrites them in
+// program order.  The LDS block is 5 KB per wave.
 //
 // trace_wave_steal() serves single-mesh scenes (triangle soups), trace_wave_steal_inst() scenes of
 // several mesh instances; scenes with analytic spheres use the per-lane walks of rt_trace_inl.h.
@@ -32,7 +31,7 @@ namespace rt {
 #ifndef RT_STEAL_STACK
 #define RT_STEAL_STACK 14
 #endif
-constexpr int kStealStack = RT_STEAL_STACK;   // LDS stack entries per lane; with 14 the block is 4.5 KB: 8 waves per SIMD
+constexpr int kStealStack = RT_STEAL_STACK;   // LDS stack entries per lane; with 14 the block is 5 KB: 7 waves per SIMD use 140 of a CU's 160 KB
 
 template <bool COUNT>
 struct StealCounters {
@@ -46,6 +45,7 @@ struct StealLds : StealCounters<COUNT> {
     int stack[kStealStack][64];
     unsigned long long best[64];
     uint32_t paySlot[64];
+    float payBeta[64], payGamma[64];   // barycentric coordinates of the hit in paySlot (closest-hit queries)
     int giveList[64];
 };
 
@@ -62,17 +62,6 @@ __device__ __forceinline__ unsigned long long wave_ballot(bool p) { return __bui
 __device__ __forceinline__ int lanes_below(unsigned long long m)
 {
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
-}
-
-// beta / gamma of the hit trace_wave_steal() reported for world-space ray (wo, wd).
-__device__ __forceinline__ void hit_barycentrics(const SceneView& sv, uint32_t slot, F3 wo, F3 wd, float& beta, float& gamma)
-{
-    const DevInstance& in = sv.inst[0];
-    F3 o, d;
-    xf_ray_inv(in.inv, sv.identityXf != 0, wo, wd, o, d);
-    const float4* tp = tri_ptr(sv, slot);
-    float t;
-    tri_test(tp[0], tp[1], tp[2], o, d, t, beta, gamma);
 }
 
 template <bool ANY, bool COUNT>
@@ -239,17 +228,17 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 const uint32_t slot = triBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
                 const float4* tp = tri_ptr(sv, slot);
                 const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                float t;
+                float t, tb, tg;
 #ifdef RT_DEV_STATS
                 dsLeafIt += 1.0f / (float)__popcll(wave_ballot(true));
 #endif
-                if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t) && t <= hlim) {
+                if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, tb, tg) && t <= hlim) {
                     if (ANY) {
                         atomicMin(&L.best[howner], 0ull);
                     } else {
                         const unsigned long long mine = pack_hit(t + 0.0f, sv.triIds[slot]);   // -0 (a ray that starts in the triangle's plane) as +0
                         const unsigned long long old = atomicMin(&L.best[howner], mine);
-                        if (mine < old && L.best[howner] == mine) L.paySlot[howner] = slot;
+                        if (mine < old && L.best[howner] == mine) { L.paySlot[howner] = slot; L.payBeta[howner] = tb; L.payGamma[howner] = tg; }
                     }
                 }
             }
@@ -289,8 +278,8 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
         r.t = hit ? __uint_as_float((uint32_t)(b >> 32)) : INFINITY;
         r.slot = L.paySlot[lane];
         r.inst = hit ? 0u : kInvalid;
-        r.beta = 0.0f;      // left to hit_barycentrics()
-        r.gamma = 0.0f;
+        r.beta = hit ? L.payBeta[lane] : 0.0f;
+        r.gamma = hit ? L.payGamma[lane] : 0.0f;
     }
     if constexpr (COUNT) { nBoxes = L.cnt[0][lane]; nTris = L.cnt[1][lane]; }
 #ifdef RT_DEV_STATS
@@ -330,15 +319,6 @@ template <bool COUNT>
 struct StealLdsInst : StealLds<COUNT> {
     uint32_t payInst[64];
 };
-
-__device__ __forceinline__ void hit_barycentrics_inst(const SceneView& sv, uint32_t inst, uint32_t slot, F3 wo, F3 wd, float& beta, float& gamma)
-{
-    const DevInstance& in = sv.inst[inst];
-    const F3 o = xf_point_inv(in.inv, wo), d = xf_vector_inv(in.inv, wd);
-    const float4* tp = tri_ptr(sv, slot);
-    float t;
-    tri_test(tp[0], tp[1], tp[2], o, d, t, beta, gamma);
-}
 
 template <bool ANY, bool COUNT>
 __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv, bool hasRay, F3 wo0, F3 wd0, float tmax,
@@ -497,14 +477,14 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     const uint32_t slot = htriBase + ((uint32_t)(~hcur) >> 4) + (uint32_t)(e >> 6);
                     const float4* tp = tri_ptr(sv, slot);
                     const float4 r0 = tp[0], r1 = tp[1], r2 = tp[2];
-                    float t;
-                    if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t) && t <= hlim) {
+                    float t, tb, tg;
+                    if (tri_test_flat(r0, r1, r2, f3(hox, hoy, hoz), f3(hdx, hdy, hdz), t, tb, tg) && t <= hlim) {
                         if (ANY) {
                             atomicMin(&L.best[howner], 0ull);
                         } else {
                             const unsigned long long mine = pack_hit(t + 0.0f, hkeyBase + sv.triIds[slot]);   // -0 as +0, see pack_hit
                             const unsigned long long old = atomicMin(&L.best[howner], mine);
-                            if (mine < old && L.best[howner] == mine) { L.paySlot[howner] = slot; L.payInst[howner] = hinst; }
+                            if (mine < old && L.best[howner] == mine) { L.paySlot[howner] = slot; L.payInst[howner] = hinst; L.payBeta[howner] = tb; L.payGamma[howner] = tg; }
                         }
                     }
                 }
@@ -555,7 +535,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
         r.t = hit ? __uint_as_float((uint32_t)(b >> 32)) : INFINITY;
         r.inst = hit ? L.payInst[lane] : kInvalid;
         r.prim = hit ? sv.triIds[r.slot] : kInvalid;
-        if (hit) hit_barycentrics_inst(sv, r.inst, r.slot, wo0, wd0, r.beta, r.gamma);
+        if (hit) { r.beta = L.payBeta[lane]; r.gamma = L.payGamma[lane]; }
     }
     if constexpr (COUNT) { nBoxes = L.cnt[0][lane]; nTris = L.cnt[1][lane]; }
     return r;

@@ -75,15 +75,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void tr
     h.t = r.t;
     h.prim = r.prim;
     h.inst = r.inst;
-    h.beta = 0.0f;
-    h.gamma = 0.0f;
-    if (r.slot != kInvalid) {
-        // the ray is read again rather than kept in registers across the traversal loop
-        const float* ro2 = ro;
-        const float* rd2 = rd;
-        asm volatile("" : "+s"(ro2), "+s"(rd2));
-        hit_barycentrics(sv, r.slot, f3(ro2[3 * i], ro2[3 * i + 1], ro2[3 * i + 2]), f3(rd2[3 * i], rd2[3 * i + 1], rd2[3 * i + 2]), h.beta, h.gamma);
-    }
+    h.beta = r.beta;
+    h.gamma = r.gamma;
     out[i] = h;
     if (COUNT) {
         counts[2 * i] = nb;

@@ -121,7 +121,7 @@ __device__ __forceinline__ bool tri_test(const float4 r0, const float4 r1, const
 // The same test as straight-line code for the cooperative leaf step, where every lane of the wave tests a triangle at once
 // and a lane that fails early would only wait for the others: same operations in the same order, the rejections
 // (written as the negations of the comparisons above, so that NaNs decide the same way) combined at the end.
-__device__ __forceinline__ bool tri_test_flat(const float4 r0, const float4 r1, const float4 r2, F3 o, F3 d, float& t)
+__device__ __forceinline__ bool tri_test_flat(const float4 r0, const float4 r1, const float4 r2, F3 o, F3 d, float& t, float& betaOut, float& gammaOut)
 {
     const float c0 = r0.w, c1 = r1.w, c2 = r2.w;
     const float pDet = (d.x * c0 - d.y * c1) + d.z * c2;
@@ -133,6 +133,8 @@ __device__ __forceinline__ bool tri_test_flat(const float4 r0, const float4 r1, 
     const float beta = p1Det * invDet;
     const float p2Det = (d.x * (r1.y * xz - r1.z * xy) - d.y * (r1.x * xz - r1.z * xx)) + d.z * (r1.x * xy - r1.y * xx);
     const float gamma = p2Det * invDet;
+    betaOut = beta;
+    gammaOut = gamma;
     return !(pDet == 0.0f) & !(t < 0.0f) & !(beta < 0.0f) & !(gamma < 0.0f) & !(gamma + beta > 1.0f);
 }
 

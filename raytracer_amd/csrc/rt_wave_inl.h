@@ -35,9 +35,7 @@ __device__ __forceinline__ TraceResult wave_closest(const SceneView& sv, bool ha
 {
     uint32_t nb = 0, nt = 0;
     if constexpr (MODE == kTraceSingle) {
-        TraceResult r = trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
-        if (r.slot != kInvalid) hit_barycentrics(sv, r.slot, o, d, r.beta, r.gamma);
-        return r;
+        return trace_wave_steal<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     } else if constexpr (MODE == kTraceInstances) {
         return trace_wave_steal_inst<false, false>(sv, has, o, d, INFINITY, lds, lane, nb, nt, sv.stealMinIdle, sv.stealLeafPct);
     } else {
