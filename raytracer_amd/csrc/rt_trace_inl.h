@@ -381,7 +381,7 @@ __device__ __forceinline__ TraceResult trace_ray(const SceneView& sv, F3 wo, F3 
 
     bool alive = true;
     while (alive) {
-        // ---- inner nodes: one 128-byte record holds the boxes of all (up to four) children ----
+        // ---- inner nodes: one record holds the boxes of all (up to four) children ----
         while (cur >= 0) {
             int c[4];
             uint32_t tested;
