@@ -71,9 +71,28 @@ constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
 #ifdef RT_SHADE_STATS
 // developer build: lanes and waves that reach marked places of the later shade passes (slot 2k = lanes, 2k + 1 = waves)
 __device__ unsigned long long g_shade_stats[64];
+__device__ unsigned long long g_shade_clocks[64][16];   // [workgroup mod 64][2k = cycles, 2k + 1 = waves]: spread so that the counting itself does not queue up
+#ifdef RT_SHADE_CLOCKS_ONLY
+#define SHADE_STAT(k, pred) do { } while (0)
+#else
 #define SHADE_STAT(k, pred) do { if (!FIRST) { const unsigned long long m_ = __ballot(pred); if (m_ != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_shade_stats[2 * (k)], (unsigned long long)__popcll(m_)); atomicAdd(&g_shade_stats[2 * (k) + 1], 1ull); } } } while (0)
+#endif
+// ... and the shader-clock cycles a wave spends between two marks
+#define SHADE_T0(k) const unsigned long long clk0_##k = FIRST ? 0ull : clock64()
+#define SHADE_T1(k) do { if (!FIRST) shade_clock_add(k, clock64() - clk0_##k); } while (0)
+__device__ __forceinline__ void shade_clock_add(int k, unsigned long long dt)
+{
+    // the lanes of a wave that are here read the clock in the same instruction: one of them reports
+    const unsigned long long m = __ballot(true);
+    if ((threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m) - 1)) {
+        atomicAdd(&g_shade_clocks[blockIdx.x & 63u][2 * k], dt);
+        atomicAdd(&g_shade_clocks[blockIdx.x & 63u][2 * k + 1], 1ull);
+    }
+}
 #else
 #define SHADE_STAT(k, pred) do { } while (0)
+#define SHADE_T0(k) do { } while (0)
+#define SHADE_T1(k) do { } while (0)
 #endif
 
 // Path state lives in 16-byte records so that every access is one full-width load or store per
@@ -326,18 +345,48 @@ __device__ __forceinline__ ShadeItem shade_regroup(const SceneView& sv, uint32_t
     return out;
 }
 
+struct ShadeArgs {
+    SceneView sv;
+    Pool pool;
+    rtgpu_render_settings st;
+    Batch batch;
+    const uint32_t* qIn;
+    uint32_t nPaths;
+    const uint32_t* cntIn;
+    uint32_t* qExt;
+    uint32_t* cnt;
+};
+
 template <bool FIRST, bool RICH>
 // five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took 98-111 of its own
 // accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and lose, and so does
 // five for the RICH variants)
-__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(SceneView sv, Pool pool, rtgpu_render_settings st, Batch batch,
-                                                    const uint32_t* __restrict__ qIn, uint32_t nPaths, const uint32_t* __restrict__ cntIn,
-                                                    uint32_t* __restrict__ qExt, uint32_t* __restrict__ cnt)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(ShadeArgs byValue)
 {
+#ifdef RT_SHADE_ARGS_BY_VALUE
+    const ShadeArgs& A = byValue;
+#else
+    // The arguments are read where they are used, through the kernel-argument segment's address, instead of through the
+    // parameter: as a parameter every field the kernel uses is loaded into scalar registers at its entry and stays there,
+    // far more than a wave has, and the compiler then keeps them in lanes of a vector register and fetches them back
+    // one v_readlane at a time (a fifth of the kernel's vector instructions).
+    const ShadeArgs& A = *(const ShadeArgs*)__builtin_amdgcn_kernarg_segment_ptr();
+#endif
+    const SceneView& sv = A.sv;
+    const Pool& pool = A.pool;
+    const rtgpu_render_settings& st = A.st;
+    const Batch& batch = A.batch;
+    const uint32_t* __restrict__ qIn = A.qIn;
+    const uint32_t nPaths = A.nPaths;
+    const uint32_t* __restrict__ cntIn = A.cntIn;
+    uint32_t* __restrict__ qExt = A.qExt;
+    uint32_t* __restrict__ cnt = A.cnt;
     // FIRST: every path of the batch; later passes: the extension queue the previous pass filled, whose length is read
     // here (the grid is sized from an upper bound the host knows, surplus workgroups find nothing to do)
     const uint32_t nIn = FIRST ? nPaths : cntIn[0];
     if (blockIdx.x * (uint32_t)kShadeBlock >= nIn) return;   // a surplus workgroup (the grid covers an upper bound of the queue): nothing to regroup or push
+    SHADE_T0(0);
+    SHADE_T0(1);
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
@@ -365,9 +414,11 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     if (sv.shadeRegroup) it = shade_regroup<kShadeBlock>(sv, st.seed, M, it, vertexGuess);   // uniform branch
     const bool active = it.active;
     const uint32_t p = it.p;
+    SHADE_T1(1);
     SHADE_STAT(0, true);
     SHADE_STAT(1, active);
     if (active) {
+        SHADE_T0(2);
         const int maxLen = st.max_path_length;
         const uint32_t s = p / M, j = it.j, i = it.i;
         const uint32_t pixel = it.pixel;
@@ -531,7 +582,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             if (sv.hasEnv) result = rgb_mul(thr, env_radiance(sv, d));
         }
 
+        SHADE_T1(2);
         if (!done) {
+            SHADE_T0(3);
             SHADE_STAT(4, true);
             // ---- vertex k: IMaterial::sampleTransport + the vertex's factor of calculatePathEnergy ----
             // Everything the vertex needs from the scene is asked for here, side by side: the triangle's shading record
@@ -608,6 +661,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             if (mat.type == RTGPU_MAT_GLOSSY) specularity = 1.0f - mat.roughness;
             else if (mat.type == RTGPU_MAT_GLASS || mat.type == RTGPU_MAT_TRANSPARENT) specularity = 1.0f;
 
+            SHADE_T1(3);
             if (caustics && (prevFlags & ST_PREV_DIFFUSE) && specularity > 0.8) {
                 done = true;
                 pushPhoton = true;
@@ -751,20 +805,41 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                     // before any variance vertex all material samples j are the same path and only j = 0 is read
                     // (resolve_kernel): the others skip the search
                     pushPhoton = passed || j == 0u;
-                } else if (mat.type == RTGPU_MAT_DIFFUSE) {
-                    // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195)
-                    const bool useNEE = rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5f;
+                } else {
+                    // DiffuseMaterial::sampleTransport / bsdf (material/DiffuseMaterial.cpp:84-103, 183-195) or
+                    // GlossyMaterial::sampleTransport / bsdf (material/GlossyMaterial.cpp:68-207).  What the two have in
+                    // common -- the choice of next-event estimation, the light sample, the stratified square of a bounce
+                    // -- is written once, so that a wave holding vertices of both kinds runs it once for all of them.
+                    const bool glossy = mat.type != RTGPU_MAT_DIFFUSE;
+                    const float roughness = mat.roughness;
+                    const bool neeEnabled = !glossy || roughness > 0;
+                    const bool useNEE = neeEnabled && rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5f;
                     if (useNEE) {
-                        SHADE_STAT(6, true);
+                        SHADE_T0(4);
+                        SHADE_STAT(6, !glossy);
+                        SHADE_STAT(8, glossy);
                         const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);   // what the vertex is worth when the light is hidden
                         if (ns.valid) {
-                            const double angle = fmaxf(0.0f, dot3(normal, ns.dir));
-                            const RGBf direct = rgb_scale_d(ns.radiance, angle);
-                            const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensityOverPi), 2.0f);
-                            const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, rgb_mul(color, value))));
+                            RGBf contribution;
+                            bool black;
+                            if (!glossy) {
+                                const double angle = fmaxf(0.0f, dot3(normal, ns.dir));
+                                const RGBf direct = rgb_scale_d(ns.radiance, angle);
+                                const RGBf value = rgb_scale_f(rgb_scale_d(direct, mat.intensityOverPi), 2.0f);
+                                contribution = rgb_mul(color, value);
+                                black = value.r == 0.0f && value.g == 0.0f && value.b == 0.0f;
+                            } else {
+                                const F3 micro = normalized3((-d) + ns.dir);
+                                const double angle = fmaxf(0.0f, dot3(micro, ns.dir));
+                                const float f = ggx_brdf(roughness, -d, ns.dir, normal, micro);
+                                const RGBf neeRadiance = rgb_scale_d(rgb_scale_d(ns.radiance, angle), f);
+                                contribution = rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color);
+                                black = neeRadiance.r == 0.0f && neeRadiance.g == 0.0f && neeRadiance.b == 0.0f;
+                            }
+                            const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, contribution)));
                             o = hitpoint + (ns.dir * 0.0001f);
                             d = ns.dir;
                             outTmax = ns.tmax;
@@ -772,95 +847,76 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                             writeAux = true;
                             // a sample worth exactly nothing (the light is behind the surface or faces away) leaves the path's value
                             // what it is when the light is hidden: no query (NaN or infinite values are not zero and are traced)
-                            pushShadow = !(sv.skipBlackShadow && value.r == 0.0f && value.g == 0.0f && value.b == 0.0f);
+                            pushShadow = !(sv.skipBlackShadow && black);
                         }
+                        SHADE_T1(4);
                     } else {
-                        const Basis3 basis = basis_from(normal);
-                        SHADE_STAT(7, true);
+                        SHADE_T0(5);
+                        SHADE_STAT(7, !glossy);
+                        SHADE_STAT(9, glossy);
+                        // the diffuse bounce stratifies over the grid's edge, the glossy one over the sample count
+                        // (material/DiffuseMaterial.cpp:98, material/GlossyMaterial.cpp:107)
                         float sx, sy;
-                        stratified_square(sampleGrid, (float)sampleI,
+                        stratified_square(glossy ? sampleCount : sampleGrid, (float)sampleI,
                                           rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
-                        const F3 l = cosine_hemisphere(sx, sy);
-                        const F3 dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
-                        const bool terminated = rand_unit_from(rp, st.seed, vk, DIM_RR) < 0.1f;
-                        if (terminated) {
-                            done = true;
-                        } else {
-                            const double angle = fmaxf(0.0f, dot3(normal, dir));
-                            const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
-                            const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
-                            const RGBf thrBefore = thr, accBefore = acc;
-                            const F3 rayDirIn = d;
-                            if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
-                            thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
-                            o = hitpoint + (dir * 0.0001f);
-                            d = dir;
-                            writeThr = true;
-                            state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
-                            if (RICH && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity 0
-                            if (caustics) {
-                                state |= ST_PREV_DIFFUSE | ST_PREV_ROUGH;
-                                const RGBf tc = rgb_mul(thrBefore, color), cb = rgb_add(accBefore, rgb_mul(thrBefore, addE));
-                                pool.cHit[p] = f4(hitpoint.x, hitpoint.y, hitpoint.z, 0.0f);
-                                pool.cDir[p] = f4(rayDirIn.x, rayDirIn.y, rayDirIn.z, 0.0f);
-                                pool.cThrColor[p] = f4(tc.r, tc.g, tc.b, 0.0f);
-                                pool.cBase[p] = f4(cb.r, cb.g, cb.b, 0.0f);
+                        if (!glossy) {
+                            const Basis3 basis = basis_from(normal);
+                            const F3 l = cosine_hemisphere(sx, sy);
+                            const F3 dir = ((basis.u * l.x) + (basis.v * l.y)) + (basis.w * l.z);
+                            const bool terminated = rand_unit_from(rp, st.seed, vk, DIM_RR) < 0.1f;
+                            if (terminated) {
+                                done = true;
+                            } else {
+                                const double angle = fmaxf(0.0f, dot3(normal, dir));
+                                const RGBf unit = rgb(1.0f, 1.0f, 1.0f);
+                                const RGBf value = rgb_scale_f(rgb_scale_d(rgb_scale_d(unit, angle), mat.intensity), 2.0f);
+                                const RGBf thrBefore = thr, accBefore = acc;
+                                const F3 rayDirIn = d;
+                                if ((RICH && sv.hasAdd)) { acc = rgb_add(acc, rgb_div_f(rgb_mul(thr, addE), 1.0f - 0.1f)); writeAcc = true; }
+                                thr = rgb_div_f(rgb_mul(thr, rgb_mul(color, value)), 1.0f - 0.1f);
+                                o = hitpoint + (dir * 0.0001f);
+                                d = dir;
+                                writeThr = true;
+                                state = (state & ~ST_K_MASK) | (uint32_t)(k + 1);
+                                if (RICH && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity 0
+                                if (caustics) {
+                                    state |= ST_PREV_DIFFUSE | ST_PREV_ROUGH;
+                                    const RGBf tc = rgb_mul(thrBefore, color), cb = rgb_add(accBefore, rgb_mul(thrBefore, addE));
+                                    pool.cHit[p] = f4(hitpoint.x, hitpoint.y, hitpoint.z, 0.0f);
+                                    pool.cDir[p] = f4(rayDirIn.x, rayDirIn.y, rayDirIn.z, 0.0f);
+                                    pool.cThrColor[p] = f4(tc.r, tc.g, tc.b, 0.0f);
+                                    pool.cBase[p] = f4(cb.r, cb.g, cb.b, 0.0f);
+                                }
+                                pushExt = true;
+                                done = true;
                             }
-                            pushExt = true;
+                        } else {
+                            const F3 micro = normalized3(vndf_sample(normal, -d, roughness, sx, sy));
+                            // getPerfectReflectionDir (GlossyMaterial.cpp:22-25): the double factor narrows to float
+                            const F3 sampleDir = d + ((float)(2.0 * (double)dot3(micro, -d)) * micro);
                             done = true;
+                            completed = true;   // a direction below the surface ends the path as an emissive black vertex (GlossyMaterial.cpp:117-122)
+                            result = rgb_mul(thr, addE);
+                            if (!(dot3(sampleDir, surfaceNormal) < 0)) {
+                                if ((RICH && sv.hasAdd)) { pend = rgb_mul(thr, addE); writePend = true; }
+                                thr = rgb_mul(thr, color);
+                                o = hitpoint + (sampleDir * 0.001f);
+                                d = sampleDir;
+                                writeThr = true;
+                                outAux = hitpoint;
+                                writeAux = true;
+                                state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
+                                if (RICH && (1.0f - roughness) < 0.8 && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity = 1 - roughness
+                                if (caustics && (1.0f - roughness) < 0.8) state |= ST_PREV_ROUGH;
+                                pushExt = true;
+                            }
                         }
-                    }
-                } else { // RTGPU_MAT_GLOSSY: GlossyMaterial::sampleTransport / bsdf (material/GlossyMaterial.cpp:68-207)
-                    const float roughness = mat.roughness;
-                    const bool neeEnabled = roughness > 0;
-                    const bool useNEE = neeEnabled && rand_unit_from(rp, st.seed, vk, DIM_NEE_CHOICE) > 0.5;
-                    if (useNEE) {
-                        SHADE_STAT(8, true);
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
-                        done = true;
-                        completed = true;
-                        result = rgb_mul(thr, addE);
-                        if (ns.valid) {
-                            const F3 micro = normalized3((-d) + ns.dir);
-                            const double angle = fmaxf(0.0f, dot3(micro, ns.dir));
-                            const float f = ggx_brdf(roughness, -d, ns.dir, normal, micro);
-                            const RGBf neeRadiance = rgb_scale_d(rgb_scale_d(ns.radiance, angle), f);
-                            const RGBf c = rgb_add(acc, rgb_mul(thr, rgb_add(addE, rgb_mul(rgb_scale_f(neeRadiance, 2.0f), color))));
-                            o = hitpoint + (ns.dir * 0.0001f);
-                            d = ns.dir;
-                            outTmax = ns.tmax;
-                            outAux = f3(c.r, c.g, c.b);
-                            writeAux = true;
-                            pushShadow = !(sv.skipBlackShadow && neeRadiance.r == 0.0f && neeRadiance.g == 0.0f && neeRadiance.b == 0.0f);
-                        }
-                    } else {
-                        SHADE_STAT(9, true);
-                        float sx, sy;
-                        stratified_square(sampleCount, (float)sampleI,
-                                          rand_unit_from(rp, st.seed, vk, DIM_SQUARE_X), rand_unit_from(rp, st.seed, vk, DIM_SQUARE_Y), sx, sy);
-                        const F3 micro = normalized3(vndf_sample(normal, -d, roughness, sx, sy));
-                        // getPerfectReflectionDir (GlossyMaterial.cpp:22-25): the double factor narrows to float
-                        const F3 sampleDir = d + ((float)(2.0 * (double)dot3(micro, -d)) * micro);
-                        done = true;
-                        completed = true;   // a direction below the surface ends the path as an emissive black vertex (GlossyMaterial.cpp:117-122)
-                        result = rgb_mul(thr, addE);
-                        if (!(dot3(sampleDir, surfaceNormal) < 0)) {
-                            if ((RICH && sv.hasAdd)) { pend = rgb_mul(thr, addE); writePend = true; }
-                            thr = rgb_mul(thr, color);
-                            o = hitpoint + (sampleDir * 0.001f);
-                            d = sampleDir;
-                            writeThr = true;
-                            outAux = hitpoint;
-                            writeAux = true;
-                            state = (state & ~ST_K_MASK) | (uint32_t)k | ST_GLOSSY_PENDING | (neeEnabled ? ST_GLOSSY_ROUGH : 0u);
-                            if (RICH && (1.0f - roughness) < 0.8 && diffuseCount < 15u) state += 1u << ST_DIFFUSE_SHIFT;   // specularity = 1 - roughness
-                            if (caustics && (1.0f - roughness) < 0.8) state |= ST_PREV_ROUGH;
-                            pushExt = true;
-                        }
+                        SHADE_T1(5);
                     }
                 }
             }
         }
+        SHADE_T0(6);
         repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
         if (pushExt || pushShadow || pushPhoton) {
             SHADE_STAT(10, true);
@@ -885,7 +941,9 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             const RGBf total = rgb_add(acc, result);
             pool.result[p] = completed ? f4(total.r, total.g, total.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
         }
+        SHADE_T1(6);
     }
+    SHADE_T0(7);
     queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p);
     if (RICH) {
         if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, cnt + 2, pushPhoton, p);   // uniform branch
@@ -895,6 +953,8 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     // the ray statistics only contain distinct rays.
     const unsigned long long rep = __ballot(pushExt && repeated);
     if (rep != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)rep) - 1)) atomicAdd(cnt + 3, (uint32_t)__popcll(rep));
+    SHADE_T1(7);
+    SHADE_T1(0);
 }
 
 // ---- shadow / connect and extend ------------------------------------------------------------------
@@ -1316,12 +1376,13 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
         const uint32_t* cntIn = step ? cnt - kPoolCounters : cnt;
         const uint32_t shadeBlocks = (bound + kShadeBlock - 1) / kShadeBlock;
         TB();
+        const ShadeArgs sa{sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt};
         if (rich) {
-            if (step == 0) launch(shade_kernel<true, true>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
-            else launch(shade_kernel<false, true>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+            if (step == 0) launch(shade_kernel<true, true>, shadeBlocks, kShadeBlock, ls, sa);
+            else launch(shade_kernel<false, true>, shadeBlocks, kShadeBlock, ls, sa);
         } else {
-            if (step == 0) launch(shade_kernel<true, false>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
-            else launch(shade_kernel<false, false>, shadeBlocks, kShadeBlock, ls, sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt);
+            if (step == 0) launch(shade_kernel<true, false>, shadeBlocks, kShadeBlock, ls, sa);
+            else launch(shade_kernel<false, false>, shadeBlocks, kShadeBlock, ls, sa);
         }
         TE(kStageShade);
         if (ln.hostCounters) {
@@ -1495,6 +1556,18 @@ struct ShadeStatsPrinter {
                                       "diffuse nee", "diffuse bounce", "glossy nee", "glossy bounce", "state written"};
         for (int k = 0; k < 11; ++k)
             std::fprintf(stderr, "shade stat %-22s lanes %14llu waves %12llu lanes/wave %.1f\n", names[k], h[2 * k], h[2 * k + 1], h[2 * k + 1] ? (double)h[2 * k] / (double)h[2 * k + 1] : 0.0);
+        static const char* regions[] = {"whole kernel", "until regrouped", "loads, pending vertex", "vertex set-up", "light sample", "bounce", "state written",
+                                        "queues"};
+        static unsigned long long c[64][16];
+        if (hipMemcpyFromSymbol(c, HIP_SYMBOL(g_shade_clocks), sizeof(c)) != hipSuccess) return;
+        unsigned long long tot[16] = {};
+        for (int b = 0; b < 64; ++b)
+            for (int k = 0; k < 16; ++k) tot[k] += c[b][k];
+        for (int k = 0; k < 8; ++k)
+            std::fprintf(stderr, "shade clock %-22s waves %12llu cycles/wave %10.0f share %.3f\n", regions[k], tot[2 * k + 1],
+                         tot[2 * k + 1] ? (double)tot[2 * k] / (double)tot[2 * k + 1] : 0.0, tot[0] ? (double)tot[2 * k] / (double)tot[0] : 0.0);
+        std::memset(c, 0, sizeof(c));
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_clocks), c, sizeof(c));
         std::memset(h, 0, sizeof(h));
         (void)hipMemcpyToSymbol(HIP_SYMBOL(g_shade_stats), h, sizeof(h));
     }
