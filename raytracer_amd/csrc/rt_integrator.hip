@@ -102,11 +102,7 @@ __device__ __forceinline__ void shade_clock_add(int k, unsigned long long dt)
 // that is reached through an index queue -- at a scattered address -- then costs one cache line, not four.
 struct PathField {
     float4* base;
-#ifdef RT_POOL_SOA
-    __device__ __forceinline__ float4& operator[](size_t p) const { return base[p]; }
-#else
     __device__ __forceinline__ float4& operator[](size_t p) const { return base[p * 4]; }
-#endif
 };
 
 struct Pool {
@@ -417,13 +413,73 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     SHADE_T1(1);
     SHADE_STAT(0, true);
     SHADE_STAT(1, active);
+    // A path's block is one 64-byte line at a scattered address.  Four lanes fetch the four records of one block (the
+    // memory pipeline then looks one line up per four lanes, not one per lane and record) and the records reach the
+    // lanes that shade the paths through the wave's tile in LDS.
+    float4 blkA = f4(0, 0, 0, 0), blkB = blkA, blkH = blkA, blkT = blkA;
+    __shared__ float4 blockTile[kShadeBlock / 64][64][4];
+    float4 (*tile)[4] = blockTile[threadIdx.x >> 6];
+    const int laneC = (int)(threadIdx.x & 63u), pieceC = laneC & 3;
+    if constexpr (!FIRST) {
+        float4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = (laneC >> 2) + 16 * r;
+            const uint32_t ps = (uint32_t)__shfl((int)p, src, 64);
+            const bool as = __shfl((int)active, src, 64) != 0;
+            v[r] = f4(0, 0, 0, 0);
+            if (as) v[r] = pool.rayA.base[(size_t)ps * 4 + pieceC];
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = (laneC >> 2) + 16 * r;
+            tile[src][(pieceC + src) & 3] = v[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        blkA = tile[laneC][(0 + laneC) & 3];
+        blkB = tile[laneC][(1 + laneC) & 3];
+        blkH = tile[laneC][(2 + laneC) & 3];
+        blkT = tile[laneC][(3 + laneC) & 3];
+    }
+    // the shading records of the hits (48 bytes each) the same way, three lanes of four per record
+    ShadeRec recC;
+    recC.q0 = recC.q1 = recC.q2 = f4(0.0f, __uint_as_float(kInvalid), 0.0f, 0.0f);
+    if constexpr (!FIRST) {
+        const uint32_t slotC = active ? __float_as_uint(blkH.y) : kInvalid;
+        float4 v[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = (laneC >> 2) + 16 * r;
+            const uint32_t ss = (uint32_t)__shfl((int)slotC, src, 64);
+            v[r] = f4(0.0f, __uint_as_float(kInvalid), 0.0f, 0.0f);
+            if (ss != kInvalid && pieceC < 3) v[r] = sv.shadeRecs[(size_t)ss * 3 + pieceC];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();   // every lane has read its block out of the tile
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int src = (laneC >> 2) + 16 * r;
+            tile[src][(pieceC + src) & 3] = v[r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        recC.q0 = tile[laneC][(0 + laneC) & 3];
+        recC.q1 = tile[laneC][(1 + laneC) & 3];
+        recC.q2 = tile[laneC][(2 + laneC) & 3];
+    }
+    // what the path leaves behind in its block: records 0 .. 3 = ray origin + limit, direction + state, hit, throughput
+    float4 outA = f4(0, 0, 0, 0), outB = outA, outT = outA;
+    uint32_t pieceMask = 0;
     if (active) {
         SHADE_T0(2);
         const int maxLen = st.max_path_length;
         const uint32_t s = p / M, j = it.j, i = it.i;
         const uint32_t pixel = it.pixel;
-        const float4 ra = FIRST ? pool.sA[s] : pool.rayA[p];
-        const float4 rb = FIRST ? pool.sB[s] : pool.rayB[p];
+        const float4 ra = FIRST ? pool.sA[s] : blkA;
+        const float4 rb = FIRST ? pool.sB[s] : blkB;
         float4 hc;
         uint32_t inst;
         if (FIRST) {
@@ -431,7 +487,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             hc = f4(ra.w, c.x, c.z, c.w);
             inst = __float_as_uint(c.y);
         } else {
-            hc = pool.hit[p];
+            hc = blkH;
             inst = sv.singleMesh ? (__float_as_uint(hc.y) != kInvalid ? 0u : kInvalid) : pool.hitInst[p];
         }
         uint32_t state = FIRST ? 0u : __float_as_uint(rb.w);
@@ -439,7 +495,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         F3 o = f3(ra.x, ra.y, ra.z);
         F3 d = f3(rb.x, rb.y, rb.z);
         RGBf thr = rgb(1.0f, 1.0f, 1.0f);
-        if (!FIRST) { const float4 tq = pool.thr[p]; thr = rgb(tq.x, tq.y, tq.z); }
+        if (!FIRST) thr = rgb(blkT.x, blkT.y, blkT.z);
         const float t = hc.x;
         const bool hit = inst != kInvalid;
         // what the path leaves behind for the next stage
@@ -595,7 +651,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             const DevInstance& in = sv.inst[sv.singleMesh ? 0u : inst];
             const uint32_t slot = __float_as_uint(hc.y);
             const float beta = hc.z, gamma = hc.w;
-            const ShadeRec rec = load_shade_rec(sv, slot);
+            const ShadeRec rec = FIRST ? load_shade_rec(sv, slot) : recC;
             const uint32_t tm = rec.material();
             F3 normal = sv.singleMesh ? hit_normal(sv.inst[0], o, d, t, slot, beta, gamma, rec) : hit_normal(in, o, d, t, slot, beta, gamma, rec);
             uint32_t mi = in.material;
@@ -920,18 +976,17 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
         if (pushExt || pushShadow || pushPhoton) {
             SHADE_STAT(10, true);
-            pool.rayA[p] = f4(o.x, o.y, o.z, outTmax);
-            pool.rayB[p] = f4(d.x, d.y, d.z, __uint_as_float(state));
-            if (writeThr) pool.thr[p] = f4(thr.r, thr.g, thr.b, 0.0f);
+            outA = f4(o.x, o.y, o.z, outTmax);
+            outB = f4(d.x, d.y, d.z, __uint_as_float(state));
+            // the first pass writes whole blocks, the hit record too, so that no cache line leaves the pass partly written
+            pieceMask = FIRST ? 7u : 3u;
+            if (writeThr) { outT = f4(thr.r, thr.g, thr.b, 0.0f); pieceMask |= 8u; }
             // a path that ends with its shadow ray has no use for its throughput any more: what the ray is worth when it
             // gets through waits in that record, inside the path's block, instead of in a cache line of its own
             if (writeAux) {
-                if (pushShadow && !pushExt && !pushPhoton) pool.thr[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
+                if (pushShadow && !pushExt && !pushPhoton) { outT = f4(outAux.x, outAux.y, outAux.z, outAuxW); pieceMask |= 8u; }
                 else pool.aux[p] = f4(outAux.x, outAux.y, outAux.z, outAuxW);
             }
-            // the first pass writes whole blocks (neighbouring lanes, neighbouring blocks): the hit record too, so that no
-            // cache line leaves the pass partly written
-            if (FIRST) pool.hit[p] = f4(0.0f, 0.0f, 0.0f, 0.0f);
             if ((RICH && sv.hasAdd) && pushExt) {
                 if (writeAcc) pool.acc[p] = f4(acc.r, acc.g, acc.b, 0.0f);
                 if (writePend) pool.accPend[p] = f4(pend.r, pend.g, pend.b, 0.0f);
@@ -942,6 +997,21 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             pool.result[p] = completed ? f4(total.r, total.g, total.b, 0.0f) : f4(0.0f, 0.0f, 0.0f, 0.0f);
         }
         SHADE_T1(6);
+    }
+    // the blocks go out the way they came in: every lane leaves its records in the tile, four lanes write one block
+    tile[laneC][(0 + laneC) & 3] = outA;
+    tile[laneC][(1 + laneC) & 3] = outB;
+    tile[laneC][(2 + laneC) & 3] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+    tile[laneC][(3 + laneC) & 3] = outT;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int src = (laneC >> 2) + 16 * r;
+        const uint32_t ps = (uint32_t)__shfl((int)p, src, 64);
+        const uint32_t m = (uint32_t)__shfl((int)pieceMask, src, 64);
+        if ((m >> pieceC) & 1u) pool.rayA.base[(size_t)ps * 4 + pieceC] = tile[src][(pieceC + src) & 3];
     }
     SHADE_T0(7);
     queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p);
@@ -1269,14 +1339,10 @@ size_t pool_carve(Pool& pool, char* base, const PoolDims& d)
         return p;
     };
     const size_t P = (size_t)d.P, S = (size_t)d.S;
-#ifdef RT_POOL_SOA
-    pool.rayA.base = (float4*)take(P * 16); pool.rayB.base = (float4*)take(P * 16); pool.hit.base = (float4*)take(P * 16);
-    pool.thr.base = (float4*)take(P * 16);
-#else
+    // (the shade kernel addresses the blocks' records as rayA.base[4 * path + 0 .. 3])
     float4* const blocks = (float4*)take(P * 64);
     pool.rayA.base = blocks; pool.rayB.base = blocks ? blocks + 1 : nullptr; pool.hit.base = blocks ? blocks + 2 : nullptr;
     pool.thr.base = blocks ? blocks + 3 : nullptr;
-#endif
     pool.hitInst = (uint32_t*)take(d.single ? 4 : P * 4);
     pool.aux = (float4*)take(P * 16); pool.result = (float4*)take(P * 16);
     pool.glassN = (float4*)take(d.glass ? P * 16 : 16); pool.glassA = (float4*)take(d.glass ? P * 16 : 16); pool.glassB = (float4*)take(d.glass ? P * 16 : 16);
