@@ -389,7 +389,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported beside the headline value")
     ap.add_argument("--no-c5", action="store_true", help="skip the 49.8 M-triangle configuration (about 40 s of scene set-up)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--profile-tag", default="r02l", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
+    ap.add_argument("--profile-tag", default="r02m", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
     args = ap.parse_args()
 
     import torch
