@@ -66,6 +66,11 @@ constexpr uint32_t ST_DIFFUSE_MASK = 15u << ST_DIFFUSE_SHIFT;
 constexpr uint32_t ST_PREV_DIFFUSE = 1u << 17;    // caustics mode: the previous vertex was a diffuse bounce (it left a callback)
 constexpr uint32_t ST_PREV_ROUGH = 1u << 18;      // caustics mode: the previous vertex was a bounce with specularity < 0.8
 
+// An entry of the extension queue: the path in the low 25 bits, above them the vertex the next shade pass will sample
+// for it (what that pass sorts its paths by before it has loaded anything of them).
+constexpr uint32_t kQueuePathBits = 25;
+constexpr uint32_t kQueuePathMask = (1u << kQueuePathBits) - 1u;
+
 constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
 
 #ifdef RT_SHADE_STATS
@@ -187,7 +192,7 @@ __device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, 
 // address are served one after the other (about 11 ns each on this chip), so one atomic per wave
 // would bound a shade pass by the number of its waves.  Every thread of the workgroup must call.
 template <int BLOCK>
-__device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool predE, uint32_t* qS, uint32_t* cS, bool predS, uint32_t value)
+__device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool predE, uint32_t* qS, uint32_t* cS, bool predS, uint32_t value, uint32_t valueE)
 {
     constexpr int WAVES = BLOCK / 64;
     __shared__ uint32_t cnt[2][WAVES];
@@ -203,7 +208,7 @@ __device__ __forceinline__ void queue_push2(uint32_t* qE, uint32_t* cE, bool pre
     }
     __syncthreads();
     const unsigned long long lt = (1ull << lane) - 1ull;
-    if (predE) qE[base[0] + cnt[0][wave] + (uint32_t)__popcll(mE & lt)] = value;
+    if (predE) qE[base[0] + cnt[0][wave] + (uint32_t)__popcll(mE & lt)] = valueE;
     if (predS) qS[base[1] + cnt[1][wave] + (uint32_t)__popcll(mS & lt)] = value;
 }
 
@@ -385,6 +390,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     SHADE_T0(1);
     const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
+    uint32_t nextVertex = 0;   // the vertex the next pass samples for a path that goes on: the one after a vertex that waits for its own ray
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     ShadeItem it;
     it.p = 0; it.pixel = 0; it.i = 0; it.j = 0;
@@ -392,20 +398,15 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     if (FIRST && it.active) it.active = pool.sLive[q / M] != 0;
     uint32_t vertexGuess = 0;
     if (it.active) {
-        it.p = FIRST ? q : qIn[q];
+        const uint32_t entry = FIRST ? q : qIn[q];
+        it.p = entry & kQueuePathMask;
         const uint32_t s0 = it.p / M;
         it.j = it.p % M;
         it.i = s0 % G;
         int px, py;
         bool pvalid;
         it.pixel = tile_pixel(st, batch, batch.pixelStart + s0 / G, px, py, pvalid);
-        if (!FIRST) {
-            // the vertex the pass will sample: the one after a vertex that waited for its own ray.  (This read also brings
-            // the path's block into the cache before the regrouped lanes ask for it: carrying the vertex in the queue
-            // entry instead, which saves the dependent read, measured no faster.)
-            const uint32_t st0 = __float_as_uint(pool.rayB[it.p].w);
-            vertexGuess = (st0 & ST_K_MASK) + ((st0 & (ST_GLOSSY_PENDING | ST_GLASS_PENDING | ST_RETRACE)) != 0u ? 1u : 0u);
-        }
+        vertexGuess = entry >> kQueuePathBits;   // the vertex the pass will sample (see the queue push below)
     }
     if (sv.shadeRegroup) it = shade_regroup<kShadeBlock>(sv, st.seed, M, it, vertexGuess);   // uniform branch
     const bool active = it.active;
@@ -973,6 +974,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             }
         }
         SHADE_T0(6);
+        nextVertex = (state & ST_K_MASK) + ((state & (ST_GLOSSY_PENDING | ST_GLASS_PENDING | ST_RETRACE)) != 0u ? 1u : 0u);
         repeated = j != 0 && (state & ST_PASSED_VAR) == 0;
         if (pushExt || pushShadow || pushPhoton) {
             SHADE_STAT(10, true);
@@ -1014,7 +1016,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         if ((m >> pieceC) & 1u) pool.rayA.base[(size_t)ps * 4 + pieceC] = tile[src][(pieceC + src) & 3];
     }
     SHADE_T0(7);
-    queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p);
+    queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p, p | (nextVertex << kQueuePathBits));
     if (RICH) {
         if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, cnt + 2, pushPhoton, p);   // uniform branch
     }
@@ -1056,7 +1058,7 @@ __device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& po
 {
     const uint32_t q = block * 64u + lane;
     const bool has = q < n;
-    const uint32_t p = queue[has ? q : 0u];
+    const uint32_t p = queue[has ? q : 0u] & kQueuePathMask;
     const float4 ra = pool.rayA[p], rb = pool.rayB[p];
     const TraceResult r = wave_closest<MODE>(sv, has, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), lds, lane);
     if (!has) return;
@@ -1103,7 +1105,7 @@ __global__ __launch_bounds__(64) void trace_stage_count_kernel(SceneView sv, Poo
         const uint32_t q = blockIdx.x * 64u + lane;
         const bool has = q < nExt;
         if (has) {
-            const uint32_t p = extQueue[q];
+            const uint32_t p = extQueue[q] & kQueuePathMask;
             const float4 ra = pool.rayA[p], rb = pool.rayB[p];
             const TraceResult r = solo_closest(sv, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), stack, lane, nb, nt);
             pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
@@ -1660,7 +1662,7 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     uint64_t capPaths = 1ull << 24; // paths resident per batch (about 110 bytes of state each); 2^23 measured 1.6 % slower on the 4K frame, 2^25 no faster
     if (const char* e = std::getenv("RTGPU_BATCH_PATHS")) {
         const long long v = std::atoll(e);
-        if (v > 0) capPaths = (uint64_t)v;
+        if (v > 0) capPaths = std::min<uint64_t>((uint64_t)v, 1ull << kQueuePathBits);   // a queue entry holds 25 bits of path
     }
     uint64_t pixelsPerBatch = std::max<uint64_t>(1, capPaths / pathsPerPixel);
     pixelsPerBatch = std::min<uint64_t>(pixelsPerBatch, nPixelsTotal);
