@@ -83,8 +83,13 @@ __device__ unsigned long long g_shade_clocks[64][16];   // [workgroup mod 64][2k
 #define SHADE_STAT(k, pred) do { if (!FIRST) { const unsigned long long m_ = __ballot(pred); if (m_ != 0ull && (threadIdx.x & 63u) == (uint32_t)(__ffsll((long long)m_) - 1)) { atomicAdd(&g_shade_stats[2 * (k)], (unsigned long long)__popcll(m_)); atomicAdd(&g_shade_stats[2 * (k) + 1], 1ull); } } } while (0)
 #endif
 // ... and the shader-clock cycles a wave spends between two marks
-#define SHADE_T0(k) const unsigned long long clk0_##k = FIRST ? 0ull : clock64()
-#define SHADE_T1(k) do { if (!FIRST) shade_clock_add(k, clock64() - clk0_##k); } while (0)
+#ifdef RT_SHADE_CLOCKS_FIRST   // the marks count in the first pass instead of in the later ones
+#define SHADE_CLOCKED(first) (first)
+#else
+#define SHADE_CLOCKED(first) (!(first))
+#endif
+#define SHADE_T0(k) const unsigned long long clk0_##k = SHADE_CLOCKED(FIRST) ? clock64() : 0ull
+#define SHADE_T1(k) do { if (SHADE_CLOCKED(FIRST)) shade_clock_add(k, clock64() - clk0_##k); } while (0)
 __device__ __forceinline__ void shade_clock_add(int k, unsigned long long dt)
 {
     // the lanes of a wave that are here read the clock in the same instruction: one of them reports
