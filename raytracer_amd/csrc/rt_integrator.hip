@@ -1252,29 +1252,43 @@ __global__ __launch_bounds__(256) void resolve_lanes_kernel(Pool pool, rtgpu_ren
     const uint32_t plc = has ? pl : 0u;
     const uint32_t G = (uint32_t)st.geometry_aa;
     RGBf px = rgb(0, 0, 0);
-    for (uint32_t i = 0; i < G; ++i) {
-        const uint32_t s = plc * G + i;
-        const bool all = pool.sLive[s] && pool.sHasVar[s];
-        // (a sample without a variance vertex only has result 0: the other lanes read nothing)
-        float4 v = f4(0.0f, 0.0f, 0.0f, 0.0f);
-        if (has && (all || j == 0u)) v = pool.result[(size_t)s * M + j];
-        float ar = v.x, ag = v.y, ab = v.z;
+    // four samples at a time: their flags are read first, then their results, so that four loads per lane are in flight
+    for (uint32_t i0 = 0; i0 < G; i0 += 4u) {
+        bool all[4];
+        float4 v[4];
 #pragma unroll
-        for (int step = 1; step < M; ++step) {
-            // row_shr:1 = 0x111; lanes without a left neighbour in their row get 0 (they are lane 0 of a group: not read)
-            ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111, 0xF, 0xF, true)) + v.x;
-            ag = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ag), 0x111, 0xF, 0xF, true)) + v.y;
-            ab = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ab), 0x111, 0xF, 0xF, true)) + v.z;
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t s = plc * G + (i0 + u < G ? i0 + u : G - 1u);
+            all[u] = pool.sLive[s] && pool.sHasVar[s];
         }
-        // lane M - 1 now holds ((r0 + r1) + ...) + r(M-1); a sample without variance is its result 0 alone, which lane 0 holds
-        RGBf m = rgb(ar, ag, ab);
-        if (all) m = rgb_scale_f(m, 1.0f / (float)M);
-        else {
-            // bring lane 0's value to lane M - 1 (M - 1 more shifts would do; one ds_bpermute is cheaper)
-            const int src = (int)(threadIdx.x & 63u) - (M - 1);
-            m.r = __shfl(v.x, src, 64); m.g = __shfl(v.y, src, 64); m.b = __shfl(v.z, src, 64);
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            const uint32_t s = plc * G + i0 + u;
+            // (a sample without a variance vertex only has result 0: the other lanes read nothing)
+            v[u] = f4(0.0f, 0.0f, 0.0f, 0.0f);
+            if (has && i0 + u < G && (all[u] || j == 0u)) v[u] = pool.result[(size_t)s * M + j];
         }
-        px.r += m.r; px.g += m.g; px.b += m.b;
+#pragma unroll
+        for (uint32_t u = 0; u < 4u; ++u) {
+            if (i0 + u >= G) break;   // uniform
+            float ar = v[u].x, ag = v[u].y, ab = v[u].z;
+#pragma unroll
+            for (int step = 1; step < M; ++step) {
+                // row_shr:1 = 0x111; lanes without a left neighbour in their row get 0 (they are lane 0 of a group: not read)
+                ar = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ar), 0x111, 0xF, 0xF, true)) + v[u].x;
+                ag = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ag), 0x111, 0xF, 0xF, true)) + v[u].y;
+                ab = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(ab), 0x111, 0xF, 0xF, true)) + v[u].z;
+            }
+            // lane M - 1 now holds ((r0 + r1) + ...) + r(M-1); a sample without variance is its result 0 alone, which lane 0 holds
+            RGBf m = rgb(ar, ag, ab);
+            if (all[u]) m = rgb_scale_f(m, 1.0f / (float)M);
+            else {
+                // bring lane 0's value to lane M - 1 (M - 1 more shifts would do; one ds_bpermute is cheaper)
+                const int src = (int)(threadIdx.x & 63u) - (M - 1);
+                m.r = __shfl(v[u].x, src, 64); m.g = __shfl(v[u].y, src, 64); m.b = __shfl(v[u].z, src, 64);
+            }
+            px.r += m.r; px.g += m.g; px.b += m.b;
+        }
     }
     if (!has || j != (uint32_t)(M - 1)) return;
     int x, y;
