@@ -146,6 +146,7 @@ def native_comm(torch, dist, api, rank, world, dev, timeout_s=90.0):
     flag = torch.tensor([ok], dtype=torch.float64, device=dev)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN)
     if float(flag.item()) == 1.0:
+        box["comm"].set_timeout_ms(int(timeout_s * 1e3))   # a peer lost later ends the run with an error instead of a hang
         return box["comm"], "rtgpu_gather_tiles_device: RCCL ncclSend / ncclRecv pairs to rank 0 + scatter kernel"
     why = box.get("error", "timed out after %.0f s" % timeout_s if th.is_alive() else "failed on another rank")
     sys.stderr.write("rank %d: native communicator unusable (%s); gathering with torch.distributed instead\n" % (rank, why))
@@ -219,7 +220,10 @@ def bench_headline(args, torch, dist, api, abi, scenes, rank, world, dev):
         finite = np.isfinite(img)
         checks = {"frame_mean": float(img[finite].mean()), "non_finite_pixels": int((~finite).any(axis=2).sum())}
     res = {"scene": sc, "cam": cam, "st": st, "handle": scene, "info": info, "elapsed": elapsed, "rays": float(rays),
-           "gather": gather_note, "checks": checks, "frame": img if rank == 0 else None}
+           "gather": gather_note, "checks": checks, "frame": img if rank == 0 else None,
+           # which gather was timed: the library's own ("native"; with one rank its scatter kernel alone) or torch.distributed
+           # standing in for it ("fallback": such a line does not measure the library's RCCL exchange)
+           "gather_kind": "native" if comm is not None else "fallback"}
     return res
 
 
@@ -425,7 +429,7 @@ def main():
         "metric": "Mrays/s (primary+secondary) and ms/frame at fixed spp, 1/2/4/8 MI355X",
         "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
-        "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "vs_baseline": None, "dtype": "f32", "data": "synthetic", "gather": res["gather_kind"],
         "config": {"workload": "north-star: path-traced frame of the blob-in-a-room scene (%d triangles, diffuse + glossy, area + point light), "
                                "%dx%d, %dx%d = %d spp, path length 9; %dx%d squares interleaved over %d GPU(s), gathered on rank 0"
                                % (res["scene"].n_triangles(), st.width, st.height, st.geometry_aa, st.material_aa, st.geometry_aa * st.material_aa,

@@ -207,14 +207,20 @@ typedef struct rtgpu_render_settings {
     int32_t width, height;                       /* FrameBuffer resolution */
     int32_t x_start, y_start, x_end, y_end;      /* half-open tile, film/Tile.h:19-23 */
     int32_t geometry_aa;                         /* geometryAAModifier (default 4) */
-    int32_t material_aa;                         /* materialAAModifier (default 32) */
+    int32_t material_aa;                         /* materialAAModifier (default 32); geometry_aa * material_aa, the paths of one
+                                                  * pixel, may not exceed RTGPU_MAX_PATHS_PER_PIXEL (RTGPU_ERR_LIMIT) */
     int32_t max_path_length;                     /* reference hard-codes 10, renderer/Renderer.cpp:130 */
     uint32_t seed;                               /* key of the counter-based RNG */
     int32_t jitter_mode;                         /* rtgpu_jitter_mode */
     int32_t n_gpus;                              /* rtgpu_render only: 0 or 1 = the scene's device; G > 1 = the frame's tile is cut into
                                                   * squares shared out over G devices of this process and gathered with RCCL (what the
-                                                  * reference does with one process per tile and --mergetiles, exe/Raytracer.cpp:260-277) */
+                                                  * reference does with one process per tile and --mergetiles, exe/Raytracer.cpp:260-277);
+                                                  * one such call at a time per scene (a second waits); the gather is given up with
+                                                  * RTGPU_ERR_COMM after RTGPU_COMM_TIMEOUT_MS (default 60 000) */
 } rtgpu_render_settings;
+
+/* A batch of paths holds whole pixels, and a path's index inside its batch travels in 25 bits of a queue entry. */
+#define RTGPU_MAX_PATHS_PER_PIXEL (1 << 25)
 
 typedef struct rtgpu_render_stats {
     uint64_t primary_rays;   /* Scene::traceRay calls from renderer/Renderer.cpp:161,170 */
@@ -302,13 +308,20 @@ int rtgpu_comm_unique_id(uint8_t id[RTGPU_COMM_ID_BYTES]);
 /* Blocks until all `world` ranks have called it with the same id. */
 int rtgpu_comm_create(const uint8_t id[RTGPU_COMM_ID_BYTES], int rank, int world, rtgpu_comm** out);
 void rtgpu_comm_destroy(rtgpu_comm* comm);
+/* How long rtgpu_gather_tiles_device may wait for its transfers (default 60 000 ms, or RTGPU_COMM_TIMEOUT_MS).  The reference's
+ * merge reads files and cannot hang (io/TileFile.cpp:29-70); a send or receive whose peer died after the communicator was
+ * made would.  When the limit passes, the communicator is aborted (ncclCommAbort), the call returns RTGPU_ERR_COMM and the
+ * handle refuses further use.  0: the gather is only enqueued, as a caller that waits on the stream itself may prefer. */
+int rtgpu_comm_set_timeout_ms(rtgpu_comm* comm, int timeout_ms);
 /* Floats in the compact buffer of `rank` (0 on bad arguments). */
 uint64_t rtgpu_tile_buffer_floats(const rtgpu_render_settings* settings, int tile_size, int rank, int world);
 /* Renderer::render for the squares of `rank` into its compact device buffer; returns when the work is complete. */
 int rtgpu_render_tiles_device(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
                               int tile_size, int rank, int world, float* d_tiles, rtgpu_render_stats* stats, void* hip_stream);
-/* Enqueues the gather on hip_stream: ranks > 0 send d_tiles, rank 0 receives and writes the tile's pixels of d_frame
- * (width * height * 3 floats on rank 0's device; ignored elsewhere).  Every rank of the communicator must call. */
+/* The gather on hip_stream: ranks > 0 send d_tiles, rank 0 receives and writes the tile's pixels of d_frame
+ * (width * height * 3 floats on rank 0's device; ignored elsewhere).  Every rank of the communicator must call.  With more
+ * than one rank the call returns when its transfers have completed or the communicator's time limit has passed (see
+ * rtgpu_comm_set_timeout_ms). */
 int rtgpu_gather_tiles_device(rtgpu_comm* comm, const rtgpu_render_settings* settings, int tile_size,
                               const float* d_tiles, float* d_frame, void* hip_stream);
 /* The last step of the gather alone: d_all_tiles holds the `world` compact buffers one after the other, each at a multiple of

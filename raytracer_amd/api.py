@@ -29,7 +29,7 @@ EXPORTS = [
     "rtgpu_gltf_load", "rtgpu_gltf_set_workdir", "rtgpu_gltf_scene_desc", "rtgpu_gltf_camera", "rtgpu_gltf_camera_count", "rtgpu_gltf_free",
     "rtgpu_write_exr", "rtgpu_write_png",
     "rtgpu_scene_build_photon_map", "rtgpu_scene_get_photons", "rtgpu_scene_set_photons", "rtgpu_scene_gather_photons",
-    "rtgpu_comm_unique_id", "rtgpu_comm_create", "rtgpu_comm_destroy", "rtgpu_tile_buffer_floats", "rtgpu_render_tiles_device",
+    "rtgpu_comm_unique_id", "rtgpu_comm_create", "rtgpu_comm_destroy", "rtgpu_comm_set_timeout_ms", "rtgpu_tile_buffer_floats", "rtgpu_render_tiles_device",
     "rtgpu_gather_tiles_device", "rtgpu_scatter_tiles_device", "rtgpu_scene_replicate", "rtgpu_render_work_device", "rtgpu_render_profile_device", "rtgpu_render_device_static",
     "rtgpu_host_alloc", "rtgpu_host_free",
 ]
@@ -89,6 +89,7 @@ def lib():
     L.rtgpu_comm_create.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
     L.rtgpu_comm_destroy.argtypes = [vp]
     L.rtgpu_comm_destroy.restype = None
+    L.rtgpu_comm_set_timeout_ms.argtypes = [vp, C.c_int]
     L.rtgpu_tile_buffer_floats.argtypes = [C.POINTER(abi.RenderSettings), C.c_int, C.c_int, C.c_int]
     L.rtgpu_tile_buffer_floats.restype = C.c_uint64
     L.rtgpu_render_tiles_device.argtypes = [vp, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int, C.c_int, C.c_int, vp,
@@ -388,6 +389,10 @@ class Comm:
     def gather_tiles_device(self, settings: abi.RenderSettings, tile_size, d_tiles, d_frame, stream=None):
         _check(lib().rtgpu_gather_tiles_device(self._h, C.byref(settings), int(tile_size), _ptr(d_tiles),
                                                _ptr(d_frame) if d_frame is not None else C.c_void_p(0), _stream_ptr(stream)))
+
+    def set_timeout_ms(self, timeout_ms: int):
+        """How long a gather may wait for its transfers before the communicator is aborted (0: the gather only enqueues)."""
+        _check(lib().rtgpu_comm_set_timeout_ms(self._h, int(timeout_ms)))
 
     def close(self):
         if getattr(self, "_h", None):

@@ -802,6 +802,7 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     for (int a = 0; a < 3; ++a) v.envRadiance[a] = (float)((double)desc->env_color[a] * desc->env_intensity);
     info.device_bytes = bytes;
     sc->info = info;
+    rt::static_workspace_prepare(device);   // rtgpu_render_device_static finds its workspace's address looked up: its first call allocates nothing either
     *out_scene = sc;
     return RTGPU_OK;
 }
@@ -938,7 +939,8 @@ static int check_settings(const rtgpu_render_settings* st)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "tile outside the frame buffer");
     if (st->geometry_aa < 1 || st->material_aa < 1 || st->max_path_length < 1)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "sample counts and path length must be >= 1");
-    if ((int64_t)st->geometry_aa * st->material_aa > (1ll << 31)) return fail(RTGPU_ERR_LIMIT, "geometry_aa * material_aa exceeds 2^31");
+    if ((int64_t)st->geometry_aa * st->material_aa > (int64_t)RTGPU_MAX_PATHS_PER_PIXEL)
+        return fail(RTGPU_ERR_LIMIT, "geometry_aa * material_aa exceeds 2^25 paths per pixel");
     if (st->max_path_length > 64) return fail(RTGPU_ERR_LIMIT, "max_path_length exceeds 64");
     if (st->jitter_mode != RTGPU_JITTER_RANDOM && st->jitter_mode != RTGPU_JITTER_CENTER)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "unknown jitter mode");

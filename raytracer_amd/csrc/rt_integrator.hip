@@ -70,6 +70,8 @@ constexpr uint32_t ST_PREV_ROUGH = 1u << 18;      // caustics mode: the previous
 // for it (what that pass sorts its paths by before it has loaded anything of them).
 constexpr uint32_t kQueuePathBits = 25;
 constexpr uint32_t kQueuePathMask = (1u << kQueuePathBits) - 1u;
+static_assert((1u << kQueuePathBits) == (uint32_t)RTGPU_MAX_PATHS_PER_PIXEL, "the path limit the header states is the queue entry's");
+static_assert(kQueuePathBits + 7 <= 32 && 64 + 1 <= (1 << 7), "a queue entry holds the path and the next vertex (at most max_path_length = 64)");
 
 constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
 
@@ -1687,7 +1689,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     pixelsPerBatch = std::min<uint64_t>(pixelsPerBatch, nPixelsTotal);
     const uint64_t P = pixelsPerBatch * pathsPerPixel;
     const uint64_t S = pixelsPerBatch * G;
-    if (P >= (1ull << 31)) { err = "geometry_aa * material_aa too large for one batch"; return hipErrorInvalidValue; }
+    // a batch holds whole pixels and a queue entry 25 bits of path: more paths per pixel than that would alias with the vertex bits
+    if (P > (1ull << kQueuePathBits)) { err = "geometry_aa * material_aa exceeds 2^25 paths per pixel"; return hipErrorInvalidValue; }
 
     // Batches are independent (disjoint pixels), so `lanes` of them are in flight at once, each on its own stream
     // with its own workspace and host thread: the thin late-bounce launches of one batch overlap with the other
@@ -1817,10 +1820,14 @@ hipError_t static_workspace(int device, void** out)
     std::lock_guard<std::mutex> lock(g_scratchMutex);
     if (device < 0 || device >= kMaxDevices) return hipErrorInvalidDevice;
     if (!g_scratchPtr[device]) {
-        hipError_t e = hipSetDevice(device);
+        int before = 0;
+        hipError_t e = hipGetDevice(&before);
+        if (e != hipSuccess) return e;
+        e = hipSetDevice(device);
         if (e != hipSuccess) return e;
         void* ptr = nullptr;
         e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+        (void)hipSetDevice(before);   // the caller's device stays what it was
         if (e != hipSuccess) return e;
         g_scratchPtr[device] = ptr;
     }
@@ -1829,6 +1836,12 @@ hipError_t static_workspace(int device, void** out)
 }
 
 } // namespace
+
+void static_workspace_prepare(int device)
+{
+    void* p = nullptr;
+    (void)static_workspace(device, &p);   // a failure is reported by the render that needs the array
+}
 
 int render_static(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* dRgb, hipStream_t stream)
 {
@@ -1840,10 +1853,10 @@ int render_static(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu
     const uint64_t pathsPerPixel = (uint64_t)G * M;
     // the largest batch whose workspace fits the array
     auto bytes_for = [&](uint64_t pixels) { Pool probe{}; return pool_carve(probe, nullptr, pool_dims(sv, pixels * pathsPerPixel, pixels * G)); };
-    if (pathsPerPixel >= (1ull << 31) || bytes_for(1) > RTGPU_STATIC_WORKSPACE_BYTES)
+    if (pathsPerPixel > (1ull << kQueuePathBits) || bytes_for(1) > RTGPU_STATIC_WORKSPACE_BYTES)
         return set_error(RTGPU_ERR_LIMIT, "geometry_aa * material_aa = " + std::to_string(pathsPerPixel) + " paths per pixel do not fit the " +
                                               std::to_string(RTGPU_STATIC_WORKSPACE_BYTES >> 20) + " MiB static workspace");
-    uint64_t lo = 1, hi = std::min<uint64_t>(nPixelsTotal, ((1ull << 31) - 1) / pathsPerPixel);
+    uint64_t lo = 1, hi = std::min<uint64_t>(nPixelsTotal, (1ull << kQueuePathBits) / pathsPerPixel);
     while (lo < hi) {
         const uint64_t mid = (lo + hi + 1) / 2;
         if (bytes_for(mid) <= RTGPU_STATIC_WORKSPACE_BYTES) lo = mid;

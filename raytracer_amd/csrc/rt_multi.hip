@@ -26,6 +26,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
@@ -167,6 +168,9 @@ struct rtgpu_comm {
     int rank = 0, world = 1, device = 0;
     float* stage = nullptr;       // rank 0: the peers' buffers, [world - 1][stride]
     uint64_t stageFloats = 0;
+    int timeoutMs = 0;            // how long a gather may take before the communicator is aborted; 0: the call only enqueues
+    hipEvent_t done = nullptr;
+    bool broken = false;          // aborted after a deadline: every later call fails
 };
 
 // What a scene keeps for rtgpu_render with n_gpus > 1: its copies on the other devices, one communicator and one stream
@@ -176,12 +180,15 @@ struct rtgpu_multi {
     std::vector<rtgpu_scene*> replicas;     // replicas[0] = null (the scene itself)
     std::vector<ncclComm_t> comms;
     std::vector<hipStream_t> streams;
+    std::vector<hipEvent_t> done;           // per rank: its part of the gather has completed
     std::vector<float*> tiles;
     std::vector<uint64_t> tileFloats;
     float* stage = nullptr;
     uint64_t stageFloats = 0;
     float* frame = nullptr;
     uint64_t frameFloats = 0;
+    int loopback = 0;                       // kLoopbackCopy / kLoopbackRccl: every rank on the scene's own device
+    uint32_t* stallFlag = nullptr;          // pinned; test hook of the loopback (a transfer that does not arrive)
 };
 
 namespace rt {
@@ -193,12 +200,14 @@ void destroy_multi(rtgpu_multi* m)
         (void)hipSetDevice(m->devices[i]);
         if (i < m->comms.size() && m->comms[i]) (void)rccl().CommDestroy(m->comms[i]);
         if (i < m->streams.size() && m->streams[i]) (void)hipStreamDestroy(m->streams[i]);
+        if (i < m->done.size() && m->done[i]) (void)hipEventDestroy(m->done[i]);
         if (i < m->tiles.size() && m->tiles[i]) (void)hipFree(m->tiles[i]);
         if (i < m->replicas.size() && m->replicas[i]) rtgpu_scene_destroy(m->replicas[i]);
     }
     if (!m->devices.empty()) (void)hipSetDevice(m->devices[0]);
     if (m->stage) (void)hipFree(m->stage);
     if (m->frame) (void)hipFree(m->frame);
+    if (m->stallFlag) (void)hipHostFree(m->stallFlag);
     delete m;
 }
 
@@ -213,37 +222,120 @@ int ensure_floats(float*& p, uint64_t& have, uint64_t need)
     return RTGPU_OK;
 }
 
-// Renderer::render over `G` devices of this process.
+// How long a gather may take before it is given up (RTGPU_COMM_TIMEOUT_MS; 0 = no limit).  A transfer between two GPUs of
+// one node takes well under a millisecond; what the limit is for is a peer that never posts its side.
+int default_timeout_ms()
+{
+    if (const char* e = std::getenv("RTGPU_COMM_TIMEOUT_MS")) {
+        const long v = std::atol(e);
+        if (v >= 0 && v <= 86400000) return (int)v;
+    }
+    return 60000;
+}
+
+// Waits until every event has completed or `timeoutMs` have gone by (0: no limit).  Returns the index of an event that
+// has not completed at the deadline, -1 when all have, -2 on a HIP error (message set).
+int wait_events(const std::vector<hipEvent_t>& events, const std::vector<int>& devices, int timeoutMs)
+{
+    const auto t0 = std::chrono::steady_clock::now();
+    size_t next = 0;
+    unsigned spins = 0;
+    while (next < events.size()) {
+        if (hipSetDevice(devices[next]) != hipSuccess) { set_error(RTGPU_ERR_HIP, "hipSetDevice failed"); return -2; }
+        const hipError_t q = hipEventQuery(events[next]);
+        if (q == hipSuccess) { ++next; continue; }
+        if (q != hipErrorNotReady) { hip_fail(q, "hipEventQuery"); return -2; }
+        if (timeoutMs > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeoutMs)) return (int)next;
+        if (++spins > 2000) std::this_thread::sleep_for(std::chrono::microseconds(50));   // the first 2000 polls spin: a frame's gather ends within them
+    }
+    return -1;
+}
+
+// Test hook of the loopback transport: a transfer that does not arrive.  One thread waits until the host releases it
+// (the deadline's abort does) or until `ticks` of the 100 MHz wall clock have passed, so the grid always drains.
+__global__ void stall_kernel(volatile uint32_t* release, unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();
+    while (*release == 0u && wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+
+enum { kLoopbackOff = 0, kLoopbackCopy = 1, kLoopbackRccl = 2 };
+// RTGPU_MULTI_LOOPBACK: every rank of rtgpu_render(n_gpus = G) on the scene's own device -- G copies of the scene, G host
+// threads, G compact buffers, the stage layout and the scatter kernel as on G devices.  "1" / "copy": device-to-device copies
+// stand in for the send / receive pairs; "rccl": the pairs go through a one-rank communicator (sends to itself).  For
+// boxes with fewer GPUs than ranks.
+int loopback_mode()
+{
+    const char* e = std::getenv("RTGPU_MULTI_LOOPBACK");
+    if (!e || !*e || std::strcmp(e, "0") == 0) return kLoopbackOff;
+    return std::strcmp(e, "rccl") == 0 ? kLoopbackRccl : kLoopbackCopy;
+}
+// RTGPU_MULTI_TEST_FAIL = replicate | stream | comm: the set-up of the next multi-GPU render fails at that step;
+// recv: rank 0 posts no receives (test hooks)
+bool test_fail_at(const char* step)
+{
+    const char* e = std::getenv("RTGPU_MULTI_TEST_FAIL");
+    return e && std::strcmp(e, step) == 0;
+}
+
+// Copies of the scene, streams, events and communicators for `G` ranks.  Built apart from the scene and attached only
+// when complete: a failure half-way leaves the scene as it was, and the next call starts over.
+int make_multi(const rtgpu_scene& scene, int G, int nDev, int loopback, rtgpu_multi** out)
+{
+    Rccl& R = rccl();
+    struct Guard {
+        rtgpu_multi* m;
+        ~Guard() { destroy_multi(m); }
+    } guard{new rtgpu_multi()};
+    rtgpu_multi* m = guard.m;
+    m->loopback = loopback;
+    m->devices.push_back(scene.device);
+    for (int d = 0; (int)m->devices.size() < G; ++d) {
+        if (loopback) m->devices.push_back(scene.device);
+        else if (d >= nDev) break;
+        else if (d != scene.device) m->devices.push_back(d);
+    }
+    m->replicas.assign((size_t)G, nullptr);
+    m->comms.assign((size_t)G, nullptr);
+    m->streams.assign((size_t)G, nullptr);
+    m->done.assign((size_t)G, nullptr);
+    m->tiles.assign((size_t)G, nullptr);
+    m->tileFloats.assign((size_t)G, 0);
+    for (int r = 1; r < G; ++r) {
+        if (test_fail_at("replicate") && r == G - 1) return set_error(RTGPU_ERR_OUT_OF_MEMORY, "copying the scene to another device: injected failure");
+        if (int rc = rtgpu_scene_replicate(&scene, m->devices[(size_t)r], &m->replicas[(size_t)r])) return rc;
+    }
+    for (int r = 0; r < G; ++r) {
+        MG_HIP(hipSetDevice(m->devices[(size_t)r]));
+        if (test_fail_at("stream") && r == G - 1) return set_error(RTGPU_ERR_HIP, "hipStreamCreateWithFlags: injected failure");
+        MG_HIP(hipStreamCreateWithFlags(&m->streams[(size_t)r], hipStreamNonBlocking));
+        MG_HIP(hipEventCreateWithFlags(&m->done[(size_t)r], hipEventDisableTiming));
+    }
+    MG_HIP(hipSetDevice(scene.device));
+    if (test_fail_at("comm")) return set_error(RTGPU_ERR_COMM, "ncclCommInitAll: injected failure");
+    if (loopback == kLoopbackOff) MG_NCCL(R.CommInitAll(m->comms.data(), G, m->devices.data()));
+    else if (loopback == kLoopbackRccl) MG_NCCL(R.CommInitAll(m->comms.data(), 1, m->devices.data()));   // one rank; every pair is a send to itself
+    else MG_HIP(hipHostMalloc((void**)&m->stallFlag, sizeof(uint32_t)));
+    guard.m = nullptr;
+    *out = m;
+    return RTGPU_OK;
+}
+
+// Renderer::render over `G` devices of this process.  One call at a time per scene (scene.multiMutex).
 int render_multi(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* rgbOut, rtgpu_render_stats* stats)
 {
     const int G = st.n_gpus;
+    const int loopback = loopback_mode();
     int nDev = 0;
     MG_HIP(hipGetDeviceCount(&nDev));
-    if (G > nDev) return set_error(RTGPU_ERR_NO_DEVICE, "settings ask for " + std::to_string(G) + " GPUs, " + std::to_string(nDev) + " present");
+    if (!loopback && G > nDev) return set_error(RTGPU_ERR_NO_DEVICE, "settings ask for " + std::to_string(G) + " GPUs, " + std::to_string(nDev) + " present");
     Rccl& R = rccl();
-    if (!R.ok()) return set_error(RTGPU_ERR_COMM, R.error);
+    if (loopback != kLoopbackCopy && !R.ok()) return set_error(RTGPU_ERR_COMM, R.error);
+    std::lock_guard<std::mutex> multiLock(scene.multiMutex);
     MG_HIP(hipSetDevice(scene.device));
-    if (scene.multi && (int)scene.multi->devices.size() != G) { destroy_multi(scene.multi); scene.multi = nullptr; }
-    if (!scene.multi) {
-        rtgpu_multi* m = new rtgpu_multi();
-        scene.multi = m;
-        m->devices.push_back(scene.device);
-        for (int d = 0; d < nDev && (int)m->devices.size() < G; ++d)
-            if (d != scene.device) m->devices.push_back(d);
-        m->replicas.assign((size_t)G, nullptr);
-        m->comms.assign((size_t)G, nullptr);
-        m->streams.assign((size_t)G, nullptr);
-        m->tiles.assign((size_t)G, nullptr);
-        m->tileFloats.assign((size_t)G, 0);
-        for (int r = 1; r < G; ++r)
-            if (int rc = rtgpu_scene_replicate(&scene, m->devices[(size_t)r], &m->replicas[(size_t)r])) return rc;
-        for (int r = 0; r < G; ++r) {
-            MG_HIP(hipSetDevice(m->devices[(size_t)r]));
-            MG_HIP(hipStreamCreateWithFlags(&m->streams[(size_t)r], hipStreamNonBlocking));
-        }
-        MG_HIP(hipSetDevice(scene.device));
-        MG_NCCL(R.CommInitAll(m->comms.data(), G, m->devices.data()));
-    }
+    if (scene.multi && ((int)scene.multi->devices.size() != G || scene.multi->loopback != loopback)) { destroy_multi(scene.multi); scene.multi = nullptr; }
+    if (!scene.multi)
+        if (int rc = make_multi(scene, G, nDev, loopback, &scene.multi)) return rc;
     rtgpu_multi& m = *scene.multi;
     const uint32_t T = (uint32_t)default_tile_size();
     const TileGrid grid = tile_grid(st, T);
@@ -282,21 +374,73 @@ int render_multi(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_
         if (rcs[(size_t)r] != RTGPU_OK) return set_error(rcs[(size_t)r], "GPU " + std::to_string(m.devices[(size_t)r]) + ": " + msgs[(size_t)r]);
 
     // ---- gather: all devices' transfers in one group, issued from this thread ------------------------------
-    MG_NCCL(R.GroupStart());
-    for (int r = 1; r < G; ++r) {
-        const uint64_t n = rank_floats(grid, (uint32_t)r, (uint32_t)G);
-        if (n == 0) continue;
-        MG_NCCL(R.Send(m.tiles[(size_t)r], n, ncclFloat, 0, m.comms[(size_t)r], m.streams[(size_t)r]));
-        MG_NCCL(R.Recv(m.stage + (uint64_t)(r - 1) * stride, n, ncclFloat, r, m.comms[0], m.streams[0]));
+    if (loopback == kLoopbackCopy) {
+        // render_wavefront has waited for its stream, so the ranks' buffers are complete: the copies only need rank 0's stream
+        if (const char* e = std::getenv("RTGPU_MULTI_TEST_STALL_MS")) {
+            *m.stallFlag = 0u;
+            hipLaunchKernelGGL(stall_kernel, dim3(1), dim3(1), 0, m.streams[0], (volatile uint32_t*)m.stallFlag, (unsigned long long)std::max(0L, std::atol(e)) * 100000ull);
+            MG_HIP(hipGetLastError());
+        }
+        for (int r = 1; r < G; ++r) {
+            const uint64_t n = rank_floats(grid, (uint32_t)r, (uint32_t)G);
+            if (n) MG_HIP(hipMemcpyAsync(m.stage + (uint64_t)(r - 1) * stride, m.tiles[(size_t)r], n * sizeof(float), hipMemcpyDeviceToDevice, m.streams[0]));
+        }
+    } else {
+        // the group is closed on every path: an error inside it is reported after ncclGroupEnd
+        ncclResult_t first = R.GroupStart();
+        const char* where = "ncclGroupStart";
+        if (first == ncclSuccess) {
+            for (int r = 1; r < G && first == ncclSuccess; ++r) {
+                const uint64_t n = rank_floats(grid, (uint32_t)r, (uint32_t)G);
+                if (n == 0) continue;
+                const bool self = loopback == kLoopbackRccl;
+                first = R.Send(m.tiles[(size_t)r], n, ncclFloat, 0, m.comms[self ? 0 : (size_t)r], m.streams[self ? 0 : (size_t)r]);
+                where = "ncclSend";
+                if (first != ncclSuccess) break;
+                if (test_fail_at("recv")) continue;   // test hook: a send whose receive is never posted
+                first = R.Recv(m.stage + (uint64_t)(r - 1) * stride, n, ncclFloat, self ? 0 : r, m.comms[0], m.streams[0]);
+                where = "ncclRecv";
+            }
+            const ncclResult_t end = R.GroupEnd();
+            if (first == ncclSuccess && end != ncclSuccess) { first = end; where = "ncclGroupEnd"; }
+        }
+        if (first != ncclSuccess) {
+            const int rc = set_error(RTGPU_ERR_COMM, std::string(where) + ": " + R.GetErrorString(first));
+            for (ncclComm_t& c : m.comms) if (c) { (void)R.CommAbort(c); c = nullptr; }
+            destroy_multi(scene.multi);   // what a failed group leaves behind is not reused
+            scene.multi = nullptr;
+            return rc;
+        }
     }
-    MG_NCCL(R.GroupEnd());
     MG_HIP(hipSetDevice(scene.device));
     if (int rc = launch_scatter(st, T, (uint32_t)G, m.tiles[0], m.stage, m.frame, m.streams[0])) return rc;
-    MG_HIP(hipMemcpyAsync(rgbOut, m.frame, frameFloats * sizeof(float), hipMemcpyDeviceToHost, m.streams[0]));
-    for (int r = G - 1; r >= 0; --r) {
+    for (int r = 0; r < G; ++r) {
         MG_HIP(hipSetDevice(m.devices[(size_t)r]));
-        MG_HIP(hipStreamSynchronize(m.streams[(size_t)r]));
+        MG_HIP(hipEventRecord(m.done[(size_t)r], m.streams[(size_t)r]));
     }
+    // (the frame is copied out after the wait: a copy into pageable host memory waits for the stream inside the runtime,
+    // where no deadline applies)
+    // ---- deadline: a transfer whose other side never arrives must not hold the caller for ever -----------------------------
+    const int timeoutMs = default_timeout_ms();
+    const int late = wait_events(m.done, m.devices, timeoutMs);
+    if (late == -2) return RTGPU_ERR_HIP;
+    if (late >= 0) {
+        const int rc = set_error(RTGPU_ERR_COMM, "the gather did not complete within " + std::to_string(timeoutMs) + " ms (rank " + std::to_string(late) +
+                                                     " of " + std::to_string(G) + " still waiting); communicators aborted");
+        if (m.stallFlag) *(volatile uint32_t*)m.stallFlag = 1u;
+        for (ncclComm_t& c : m.comms) if (c) { (void)R.CommAbort(c); c = nullptr; }   // ends the transfer kernels that wait for their peers
+        for (int r = 0; r < G; ++r) {
+            (void)hipSetDevice(m.devices[(size_t)r]);
+            (void)hipStreamSynchronize(m.streams[(size_t)r]);
+        }
+        destroy_multi(scene.multi);
+        scene.multi = nullptr;
+        (void)hipSetDevice(scene.device);
+        return rc;
+    }
+    MG_HIP(hipSetDevice(scene.device));
+    MG_HIP(hipMemcpyAsync(rgbOut, m.frame, frameFloats * sizeof(float), hipMemcpyDeviceToHost, m.streams[0]));
+    MG_HIP(hipStreamSynchronize(m.streams[0]));
     if (stats) {
         *stats = rtgpu_render_stats{};
         for (const rtgpu_render_stats& s : rstats) {
@@ -353,7 +497,17 @@ int rtgpu_comm_create(const uint8_t id[RTGPU_COMM_ID_BYTES], int rank, int world
     cm->rank = rank;
     cm->world = world;
     cm->device = device;
+    cm->timeoutMs = default_timeout_ms();
+    if (hipEventCreateWithFlags(&cm->done, hipEventDisableTiming) != hipSuccess) cm->done = nullptr;   // without it the gather only enqueues
     *out = cm;
+    return RTGPU_OK;
+}
+
+int rtgpu_comm_set_timeout_ms(rtgpu_comm* c, int timeout_ms)
+{
+    using namespace rt;
+    if (!c || timeout_ms < 0) return set_error(RTGPU_ERR_INVALID_ARGUMENT, "null communicator / negative time limit");
+    c->timeoutMs = timeout_ms;
     return RTGPU_OK;
 }
 
@@ -362,6 +516,7 @@ void rtgpu_comm_destroy(rtgpu_comm* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stage) (void)hipFree(c->stage);
+    if (c->done) (void)hipEventDestroy(c->done);
     if (c->comm) (void)rt::rccl().CommDestroy(c->comm);
     delete c;
 }
@@ -381,6 +536,8 @@ int rtgpu_render_tiles_device(const rtgpu_scene* scene, const rtgpu_camera* came
     if (int rc = check_tiles(settings, tile_size, rank, world)) return rc;
     if (settings->geometry_aa < 1 || settings->material_aa < 1 || settings->max_path_length < 1 || settings->max_path_length > 64)
         return set_error(RTGPU_ERR_INVALID_ARGUMENT, "sample counts and path length out of range");
+    if ((int64_t)settings->geometry_aa * settings->material_aa > (int64_t)RTGPU_MAX_PATHS_PER_PIXEL)
+        return set_error(RTGPU_ERR_LIMIT, "geometry_aa * material_aa exceeds 2^25 paths per pixel");
     if (camera->aperture < 0.0 || (camera->aperture > 0.0 && settings->geometry_aa < 2))
         return set_error(RTGPU_ERR_INVALID_ARGUMENT, "a thin-lens camera (aperture > 0) needs geometry_aa >= 2");
     if (!d_tiles && rtgpu_tile_buffer_floats(settings, tile_size, rank, world)) return set_error(RTGPU_ERR_INVALID_ARGUMENT, "tile buffer is null");
@@ -412,24 +569,53 @@ int rtgpu_gather_tiles_device(rtgpu_comm* comm, const rtgpu_render_settings* set
     const uint64_t mine = rank_floats(grid, (uint32_t)comm->rank, (uint32_t)comm->world);
     if (mine && !d_tiles) return set_error(RTGPU_ERR_INVALID_ARGUMENT, "tile buffer is null");
     if (comm->rank == 0 && !d_frame) return set_error(RTGPU_ERR_INVALID_ARGUMENT, "frame buffer is null on rank 0");
+    if (comm->broken) return set_error(RTGPU_ERR_COMM, "the communicator was aborted after a gather ran out of time");
     Rccl& R = rccl();
     const hipStream_t stream = (hipStream_t)hip_stream;
     MG_HIP(hipSetDevice(comm->device));
-    if (comm->rank != 0) {
-        if (mine) MG_NCCL(R.Send(d_tiles, mine, ncclFloat, 0, comm->comm, stream));
-        return RTGPU_OK;
-    }
+    // Aborts the communicator: what has been enqueued stops waiting for its peers, and the handle refuses further use.
+    auto give_up = [&](const std::string& why) -> int {
+        const int rc = set_error(RTGPU_ERR_COMM, why);
+        if (comm->comm) { (void)R.CommAbort(comm->comm); comm->comm = nullptr; }
+        comm->broken = true;
+        (void)hipStreamSynchronize(stream);
+        return rc;
+    };
     const uint64_t stride = rank_floats(grid, 0, (uint32_t)comm->world);
-    if (comm->world > 1) {
-        if (int rc = ensure_floats(comm->stage, comm->stageFloats, stride * (uint64_t)(comm->world - 1))) return rc;
-        MG_NCCL(R.GroupStart());
-        for (int r = 1; r < comm->world; ++r) {
-            const uint64_t n = rank_floats(grid, (uint32_t)r, (uint32_t)comm->world);
-            if (n) MG_NCCL(R.Recv(comm->stage + (uint64_t)(r - 1) * stride, n, ncclFloat, r, comm->comm, stream));
+    if (comm->rank != 0) {
+        if (mine) {
+            const ncclResult_t r = R.Send(d_tiles, mine, ncclFloat, 0, comm->comm, stream);
+            if (r != ncclSuccess) return give_up(std::string("ncclSend: ") + R.GetErrorString(r));
         }
-        MG_NCCL(R.GroupEnd());
+    } else {
+        if (comm->world > 1) {
+            if (int rc = ensure_floats(comm->stage, comm->stageFloats, stride * (uint64_t)(comm->world - 1))) return rc;
+            // the group is closed on every path: an error inside it is reported after ncclGroupEnd
+            ncclResult_t first = R.GroupStart();
+            const char* where = "ncclGroupStart";
+            if (first == ncclSuccess) {
+                for (int r = 1; r < comm->world && first == ncclSuccess; ++r) {
+                    const uint64_t n = rank_floats(grid, (uint32_t)r, (uint32_t)comm->world);
+                    if (n) first = R.Recv(comm->stage + (uint64_t)(r - 1) * stride, n, ncclFloat, r, comm->comm, stream);
+                    where = "ncclRecv";
+                }
+                const ncclResult_t end = R.GroupEnd();
+                if (first == ncclSuccess && end != ncclSuccess) { first = end; where = "ncclGroupEnd"; }
+            }
+            if (first != ncclSuccess) return give_up(std::string(where) + ": " + R.GetErrorString(first));
+        }
+        if (int rc = launch_scatter(*settings, (uint32_t)tile_size, (uint32_t)comm->world, d_tiles, comm->stage, d_frame, stream)) return rc;
     }
-    return launch_scatter(*settings, (uint32_t)tile_size, (uint32_t)comm->world, d_tiles, comm->stage, d_frame, stream);
+    if (comm->timeoutMs > 0 && comm->done && comm->world > 1) {
+        // the deadline: a peer that died after the communicator was made never posts its side, and the transfer kernel on
+        // this device would wait for it for ever
+        MG_HIP(hipEventRecord(comm->done, stream));
+        const int late = wait_events({comm->done}, {comm->device}, comm->timeoutMs);
+        if (late == -2) return RTGPU_ERR_HIP;
+        if (late >= 0) return give_up("the gather did not complete within " + std::to_string(comm->timeoutMs) + " ms on rank " + std::to_string(comm->rank) +
+                                      " of " + std::to_string(comm->world) + "; communicator aborted");
+    }
+    return RTGPU_OK;
 }
 
 int rtgpu_scene_replicate(const rtgpu_scene* src, int device, rtgpu_scene** out)
@@ -460,7 +646,7 @@ int rtgpu_scene_replicate(const rtgpu_scene* src, int device, rtgpu_scene** out)
             if (e != hipSuccess) break;
             *(const void**)((char*)&sc->view + a.viewOffset) = p;
             sc->arrays.push_back(a);
-            e = hipMemcpyPeer(p, device, from, src->device, a.bytes);
+            e = device == src->device ? hipMemcpy(p, from, a.bytes, hipMemcpyDeviceToDevice) : hipMemcpyPeer(p, device, from, src->device, a.bytes);
         }
         (void)hipSetDevice(before);
         if (e != hipSuccess) {
@@ -468,6 +654,7 @@ int rtgpu_scene_replicate(const rtgpu_scene* src, int device, rtgpu_scene** out)
             delete sc;
             return hip_fail(e, "copying the scene to another device");
         }
+        static_workspace_prepare(device);
         *out = sc;
         return RTGPU_OK;
     });

@@ -386,8 +386,11 @@ int install_photon_map(rtgpu_scene& scene, int mode, int depth)
     SceneView& v = scene.view;
     PH_HIP(hipSetDevice(scene.device));
     // copies of the scene on other devices (multi-GPU renders) hold the old map: they are made again when next needed
-    destroy_multi(scene.multi);
-    scene.multi = nullptr;
+    {
+        std::lock_guard<std::mutex> multiLock(scene.multiMutex);
+        destroy_multi(scene.multi);
+        scene.multi = nullptr;
+    }
     for (const void* p : {(const void*)v.kdPos, (const void*)v.kdNormal, (const void*)v.kdEnergy})
         if (p) (void)hipFree(const_cast<void*>(p));
     scene.set_array(&SceneView::kdPos, (const float4*)nullptr, 0);

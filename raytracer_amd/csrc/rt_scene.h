@@ -43,6 +43,7 @@ struct rtgpu_scene {
     mutable rt::RenderCache* renderCache = nullptr;
     mutable rt::HostPipe* hostPipe = nullptr;
     mutable rtgpu_multi* multi = nullptr;
+    mutable std::mutex multiMutex;       // a multi-GPU render holds it from set-up to the end of the gather: one such call at a time per scene
     void release();
     // Registers / replaces the array behind a pointer member of `view`.
     template <typename T>
@@ -89,6 +90,9 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
 void destroy_multi(rtgpu_multi*);
 // rtgpu_render_device_static: the whole call enqueued on `stream`, workspace in the library's fixed device array.
 int render_static(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* dRgb, hipStream_t stream);
+// Looks the static workspace's address on `device` up (once per device; the code object's load is what places the array
+// there).  Called when a scene is made on a device, so that by the time a render can be asked for nothing is left to set up.
+void static_workspace_prepare(int device);
 // rtgpu_render over settings.n_gpus devices of this process (rt_multi.hip).
 int render_multi_entry(const rtgpu_scene& scene, const rtgpu_camera& cam, const rtgpu_render_settings& st, float* rgbOut, rtgpu_render_stats* stats);
 

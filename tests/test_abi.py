@@ -82,6 +82,13 @@ def test_argument_errors_without_a_gpu():
     assert b"Invalid tile bounds" in lib.rtgpu_last_error()  # film/Tile.cpp:11
     assert lib.rtgpu_generate_primary_device(None, C.byref(st), 0, None, None, None) == 5
     assert b"No camera in scene." in lib.rtgpu_last_error()  # renderer/Renderer.cpp:318
+    # one pixel's paths must fit the 25 bits a queue entry has for the path: 2^25 is the last count accepted
+    st = abi.make_settings(16, 16, geometry_aa=1 << 13, material_aa=(1 << 12) + 1)
+    assert lib.rtgpu_generate_primary_device(C.byref(cam), C.byref(st), 0, None, None, None) == 6
+    assert b"2^25" in lib.rtgpu_last_error()
+    st = abi.make_settings(16, 16, geometry_aa=1 << 13, material_aa=1 << 12)
+    assert lib.rtgpu_generate_primary_device(C.byref(cam), C.byref(st), 0, None, None, None) == 1   # accepted; the null buffers are what fails
+    assert lib.rtgpu_comm_set_timeout_ms(None, 5) == 1
 
 
 def test_packed_scene_validation():
