@@ -633,13 +633,8 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
         info.n_leaves += top.leafCount;
         info.max_depth = top.maxDepth + 1 + info.max_depth;
     }
-#if RT_NODE_Q8
     if (nodes.size() * sizeof(NodeQ64) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "tree nodes exceed 4 GiB (2^26 four-way nodes)");
     const std::vector<NodeQ64> deviceNodes = quantize_tree4(nodes, threads);
-#else
-    if (nodes.size() * sizeof(Node128) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "tree nodes exceed 4 GiB (2^25 four-way nodes)");
-    const std::vector<Node128>& deviceNodes = nodes;
-#endif
     if (tris.size() * sizeof(TriRec) >= (1ull << 32)) return fail(RTGPU_ERR_LIMIT, "triangle records exceed 4 GiB (89 M triangles)");
     info.n_nodes = nodes.size();
     for (uint32_t i = 0; i < nInst; ++i) {

@@ -64,10 +64,10 @@ __device__ __forceinline__ int lanes_below(unsigned long long m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
-template <bool ANY, bool COUNT>
-__device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, bool hasRay, F3 wo, F3 wd, float tmax,
-                                                        StealLds<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
-                                                        const int minIdle = 1, const int leafPct = 48)
+template <bool ANY, bool COUNT, bool WIDE>
+__device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv, bool hasRay, F3 wo, F3 wd, float tmax,
+                                                             StealLds<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
+                                                             const int minIdle, const int leafPct)
 {
     const DevInstance& in = sv.inst[0];
     const uint32_t nodeBase = in.root, triBase = in.triBase;
@@ -170,7 +170,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
                 __builtin_amdgcn_sched_barrier(0);   // keeps the LDS read in front of the loads below
                 int c[4];
                 uint32_t tested;
-                const int nh = node4_hits<!ANY>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                const int nh = node4_hits<!ANY, WIDE>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
                 if (COUNT) wb += tested;
 #ifdef RT_DEV_STATS
                 dsNodeIt += 1.0f / (float)__popcll(wave_ballot(true));
@@ -297,6 +297,21 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
     }
 #endif
     return r;
+}
+
+// The walk with the plain box decode, or -- when some ray of the wave starts farther from the tree than the plain decode's
+// rounding allows (plane_offsets, far_from_tree) -- the same walk with the widened decode.
+template <bool ANY, bool COUNT>
+__device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, bool hasRay, F3 wo, F3 wd, float tmax,
+                                                        StealLds<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
+                                                        const int minIdle = 1, const int leafPct = 48)
+{
+    const DevInstance& in = sv.inst[0];
+    F3 o, d;
+    xf_ray_inv(in.inv, sv.identityXf != 0, wo, wd, o, d);
+    const bool wide = wave_ballot(hasRay && far_from_tree(node_ptr(sv, in.root), o)) != 0ull;
+    if (wide) return trace_wave_steal_walk<ANY, COUNT, true>(sv, hasRay, wo, wd, tmax, L, lane, nBoxes, nTris, minIdle, leafPct);
+    return trace_wave_steal_walk<ANY, COUNT, false>(sv, hasRay, wo, wd, tmax, L, lane, nBoxes, nTris, minIdle, leafPct);
 }
 
 // ---- instanced scenes ------------------------------------------------------------------------
@@ -433,7 +448,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
                 int c[4];
                 uint32_t tested;
-                const int nh = node4_hits<!ANY>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);
+                const int nh = node4_hits<!ANY, true>(node_ptr(sv, nodeBase + (uint32_t)cur), o, inv, tlim, c, tested);   // (object-space rays of scaled instances: always the widened decode)
                 if (COUNT) wb += tested;
                 if (nh > 3) push(c[3]);
                 if (nh > 2) push(c[2]);

@@ -55,42 +55,13 @@ __device__ __forceinline__ bool slab_test(float lox, float loy, float loz, float
     return a <= b;
 }
 
-// Slab test for trees whose boxes are conservative (every mesh tree: triangle boxes are padded by
-// 1e-4, shape/TriangleMesh.cpp:177-191; and the library's own top-level tree over such meshes).
-// There the box test only prunes -- the closest hit is the same whatever tree and whatever box
-// arithmetic is used, as long as no box containing a hit is rejected -- so it is written for
-// speed: v_min/v_max (which drop a NaN operand: a 0*inf slab then counts as passed, never as a
-// rejection) and, unlike the reference (which accepts boxes that lie entirely behind the ray
-// origin), boxes whose exit distance is negative are skipped: they cannot contain a hit with t >= 0.
-__device__ __forceinline__ bool slab_fast(float lox, float loy, float loz, float hix, float hiy, float hiz,
-                                          F3 o, F3 inv, float tlimit, float& t0)
-{
-    // (plane - o) * (1/d) like the reference: subtracting first keeps the error relative to the
-    // result.  (fma(plane, 1/d, -o/d) would save instructions but cancels catastrophically for rays
-    // nearly parallel to an axis and then rejects boxes that contain hits.)
-    const float tx1 = (lox - o.x) * inv.x, tx2 = (hix - o.x) * inv.x;
-    const float ty1 = (loy - o.y) * inv.y, ty2 = (hiy - o.y) * inv.y;
-    const float tz1 = (loz - o.z) * inv.z, tz2 = (hiz - o.z) * inv.z;
-    const float tnear = fmaxf(fmaxf(fminf(tx1, tx2), fminf(ty1, ty2)), fmaxf(fminf(tz1, tz2), 0.0f));
-    const float tfar = fminf(fminf(fmaxf(tx1, tx2), fmaxf(ty1, ty2)), fminf(fmaxf(tz1, tz2), tlimit));
-    t0 = tnear;
-    return tnear <= tfar;
-}
-
-// slab_fast on a box stored as (lo, hi) pairs per axis: the two planes of an axis go through one packed
-// subtract and one packed multiply (v_pk_add_f32 / v_pk_mul_f32, each an IEEE operation per half, so the
-// result equals slab_fast's).
+// Box tests in trees whose boxes are conservative (every mesh tree: triangle boxes are padded by 1e-4,
+// shape/TriangleMesh.cpp:177-191; and the library's own top-level tree over such meshes) only prune: the closest hit is
+// the same whatever tree and whatever box arithmetic is used, as long as no box containing a hit is rejected.  They are
+// therefore written for speed (slab_quantised below): v_min / v_max, which drop a NaN operand (a 0 * inf slab then counts
+// as passed, never as a rejection), and -- unlike the reference, which accepts boxes that lie entirely behind the ray
+// origin -- boxes whose exit distance is negative are skipped: they cannot contain a hit with t >= 0.
 typedef float Pair __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ bool slab_pairs(float lox, float hix, float loy, float hiy, float loz, float hiz,
-                                           F3 o, F3 inv, float tlimit, float& t0)
-{
-    const Pair px = {lox, hix}, py = {loy, hiy}, pz = {loz, hiz};
-    const Pair tx = (px - o.x) * inv.x, ty = (py - o.y) * inv.y, tz = (pz - o.z) * inv.z;
-    const float tnear = fmaxf(fmaxf(fminf(tx.x, tx.y), fminf(ty.x, ty.y)), fmaxf(fminf(tz.x, tz.y), 0.0f));
-    const float tfar = fminf(fminf(fmaxf(tx.x, tx.y), fmaxf(ty.x, ty.y)), fminf(fmaxf(tz.x, tz.y), tlimit));
-    t0 = tnear;
-    return tnear <= tfar;
-}
 
 // Triangle::intersect (math/Triangle.h:34-101) on a TriRec.  c0..c2 are the cofactors
 // (e1.y*e2.z-e1.z*e2.y), (e1.x*e2.z-e1.z*e2.x), (e1.x*e2.y-e1.y*e2.x) that both the pDet and
@@ -193,31 +164,35 @@ __device__ __forceinline__ void xf_ray_inv(const double* m, bool identity, F3 wo
 // checks that both arrays are smaller than 4 GiB.
 __device__ __forceinline__ const float4* node_ptr(const SceneView& sv, uint32_t node)
 {
-#if RT_NODE_Q8
     return (const float4*)((const char*)sv.nodes + (node << 6));
-#else
-    return (const float4*)((const char*)sv.nodes + (node << 7));
-#endif
 }
 
-// One step at an inner node of a four-way tree (NodeQ64; Node128 in a build with RT_NODE_Q8=0): the boxes of its children against the ray, and the children that
-// are hit ordered by entry distance.  c[0 .. n-1] = their references, nearest first; returns n.  `tested` = boxes tested
-// (the node's real children).  Child boxes only prune (see slab_fast), so the order is a heuristic, not part of the result.
-#if RT_NODE_Q8
-// The slab test on a child box given by its quantised planes (NodeQ64): plane = q * step + (grid origin - ray origin), one
-// packed fma per axis for both planes, times 1/d.  The plane words arrive with the plane the ray meets first in the lower
-// byte of each pair (node4_hits swaps the bytes of an axis the ray runs down), so the entry and exit distances need no
-// min / max per axis.  (near, far) = bytes `shift` and `shift + 8` of the words.
-__device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_t wz, int shift, Pair stepX, Pair stepY, Pair stepZ,
-                                               Pair cx, Pair cy, Pair cz, Pair invX, Pair invY, Pair invZ, float tlimit, float& t0)
+// Whether a ray that starts at `o` (in the tree's space) may be so far from the tree rooted at `root` that the decode's
+// rounding needs the widened form (plane_offsets): farther than 256 units from the farthest plane of the root's grid.
+__device__ __forceinline__ bool far_from_tree(const float4* root, F3 o)
+{
+    const float4 q0 = root[0], q1 = root[1];
+    const float hx = fmaf(255.0f, q0.w, q0.x), hy = fmaf(255.0f, q1.x, q0.y), hz = fmaf(255.0f, q1.y, q0.z);
+    const float dx = fmaxf(fabsf(o.x - q0.x), fabsf(o.x - hx)), dy = fmaxf(fabsf(o.y - q0.y), fabsf(o.y - hy)), dz = fmaxf(fabsf(o.z - q0.z), fabsf(o.z - hz));
+    return !(fmaxf(fmaxf(dx, dy), dz) < 256.0f);   // (a NaN distance counts as far)
+}
+
+// The slab test on a child box given by its quantised planes (NodeQ64).  A plane's distance along the ray is
+//   (origin + q * step - o) / d  =  q * (step / d) + (origin - o) / d  =  fma(q, A, B)
+// with A and B formed once per node and axis (node4_hits) and shared by the eight planes of that axis: one packed fma per
+// child and axis for both planes.  The plane words arrive with the plane the ray meets first in the lower byte of each pair
+// (node4_hits swaps the bytes of an axis the ray runs down), so the entry and exit distances need no min / max per axis.
+// (near, far) = bytes `shift` and `shift + 8` of the words; bx.x / bx.y = B for the near / far plane.
+__device__ __forceinline__ bool slab_quantised(uint32_t wx, uint32_t wy, uint32_t wz, int shift, Pair ax, Pair ay, Pair az,
+                                               Pair bx, Pair by, Pair bz, float tlimit, float& t0)
 {
     const Pair qx = {(float)((wx >> shift) & 0xFFu), (float)((wx >> (shift + 8)) & 0xFFu)};
     const Pair qy = {(float)((wy >> shift) & 0xFFu), (float)((wy >> (shift + 8)) & 0xFFu)};
     const Pair qz = {(float)((wz >> shift) & 0xFFu), (float)((wz >> (shift + 8)) & 0xFFu)};
-    const Pair tx = __builtin_elementwise_fma(qx, stepX, cx) * invX;
-    const Pair ty = __builtin_elementwise_fma(qy, stepY, cy) * invY;
-    const Pair tz = __builtin_elementwise_fma(qz, stepZ, cz) * invZ;
-    // v_max3 / v_min3 drop a NaN operand (0 * inf: the ray lies in the plane and runs along it): that slab counts as passed
+    const Pair tx = __builtin_elementwise_fma(qx, ax, bx);
+    const Pair ty = __builtin_elementwise_fma(qy, ay, by);
+    const Pair tz = __builtin_elementwise_fma(qz, az, bz);
+    // v_max3 / v_min3 drop a NaN operand (0 * inf, inf - inf: the ray runs along the axis' planes): that slab counts as passed
     const float tnear = fmaxf(fmaxf(fmaxf(tx.x, ty.x), tz.x), 0.0f);
     const float tfar = fminf(fminf(fminf(tx.y, ty.y), tz.y), tlimit);
     t0 = tnear;
@@ -229,38 +204,43 @@ __device__ __forceinline__ uint32_t near_first(uint32_t word, float invd)
     const uint32_t sel = 0x03020100u ^ ((uint32_t)(__float_as_int(invd) >> 31) & 0x01010101u);
     return __builtin_amdgcn_perm(word, word, sel);
 }
-#endif
+// B = (grid origin - ray origin) / d for the near and the far planes of an axis.  Rounding puts a decoded distance off the
+// exact one by up to 2^-22 of B (the subtraction, the two products and the fma), which is nothing next to the 1e-4 the
+// reference pads every triangle's box with (shape/TriangleMesh.cpp:177-191) as long as the node is nearer than a few hundred
+// units; WIDE (chosen per wave: some ray of the wave may be farther than that from its tree, or the tree's boxes have less
+// room) moves the near distances down and the far distances up by 2^-21 of |B|, so that the decoded box contains the exact
+// one at any distance.
+template <bool WIDE>
+__device__ __forceinline__ Pair plane_offsets(float b)
+{
+    if constexpr (!WIDE) return Pair{b, b};
+    constexpr float k = 4.76837158203125e-07f;   // 2^-21
+    return Pair{__builtin_fmaf(-fabsf(b), k, b), __builtin_fmaf(fabsf(b), k, b)};
+}
 
+// One step at an inner node of a four-way tree (NodeQ64): the boxes of its children against the ray, and the children that
+// are hit ordered by entry distance.  c[0 .. n-1] = their references, nearest first; returns n.  `tested` = boxes tested
+// (the node's real children).  Child boxes only prune (see above), so the order is a heuristic, not part of the result.
 // ORDERED = false (any-hit queries, where the first hit found ends the search and no child is nearer to the answer than
 // another): the children that are hit come first, in the node's own order -- the exchanges then move references only and
 // their conditions are mask arithmetic, about 20 vector instructions fewer per step.
-template <bool ORDERED = true>
+template <bool ORDERED = true, bool WIDE = true>
 __device__ __forceinline__ int node4_hits(const float4* np, F3 o, F3 inv, float tlim, int c[4], uint32_t& tested)
 {
     float t0, t1, t2, t3;
-#if RT_NODE_Q8
     const float4 q0 = np[0], q1 = np[1], q2 = np[2], q6 = np[3];
     int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
-    const float ox = q0.x - o.x, oy = q0.y - o.y, oz = q0.z - o.z;
-    const Pair cx = {ox, ox}, cy = {oy, oy}, cz = {oz, oz};
-    const Pair sx = {q0.w, q0.w}, sy = {q1.x, q1.x}, sz = {q1.y, q1.y};
     const float ivx = inv.x, ivy = inv.y, ivz = inv.z;   // (as scalars: a pair taken from two fields of the struct goes through private memory)
-    const Pair ix = {ivx, ivx}, iy = {ivy, ivy}, iz = {ivz, ivz};
+    const Pair bx = plane_offsets<WIDE>((q0.x - o.x) * ivx), by = plane_offsets<WIDE>((q0.y - o.y) * ivy), bz = plane_offsets<WIDE>((q0.z - o.z) * ivz);
+    const float sx = q0.w * ivx, sy = q1.x * ivy, sz = q1.y * ivz;
+    const Pair ax = {sx, sx}, ay = {sy, sy}, az = {sz, sz};
     const uint32_t x01 = near_first(__float_as_uint(q1.z), ivx), x23 = near_first(__float_as_uint(q1.w), ivx);
     const uint32_t y01 = near_first(__float_as_uint(q2.x), ivy), y23 = near_first(__float_as_uint(q2.y), ivy);
     const uint32_t z01 = near_first(__float_as_uint(q2.z), ivz), z23 = near_first(__float_as_uint(q2.w), ivz);
-    const bool h0 = slab_quantised(x01, y01, z01, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t0);                      // the first child always exists
-    const bool h1 = slab_quantised(x01, y01, z01, 16, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t1) && c1 != kEmptyChild;
-    const bool h2 = slab_quantised(x23, y23, z23, 0, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t2) && c2 != kEmptyChild;
-    const bool h3 = slab_quantised(x23, y23, z23, 16, sx, sy, sz, cx, cy, cz, ix, iy, iz, tlim, t3) && c3 != kEmptyChild;
-#else
-    const float4 q0 = np[0], q1 = np[1], q2 = np[2], q3 = np[3], q4 = np[4], q5 = np[5], q6 = np[6];
-    int c0 = __float_as_int(q6.x), c1 = __float_as_int(q6.y), c2 = __float_as_int(q6.z), c3 = __float_as_int(q6.w);
-    const bool h0 = slab_pairs(q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, o, inv, tlim, t0);                      // the first child always exists
-    const bool h1 = slab_pairs(q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, o, inv, tlim, t1) && c1 != kEmptyChild;
-    const bool h2 = slab_pairs(q3.x, q3.y, q3.z, q3.w, q4.x, q4.y, o, inv, tlim, t2) && c2 != kEmptyChild;
-    const bool h3 = slab_pairs(q4.z, q4.w, q5.x, q5.y, q5.z, q5.w, o, inv, tlim, t3) && c3 != kEmptyChild;
-#endif
+    const bool h0 = slab_quantised(x01, y01, z01, 0, ax, ay, az, bx, by, bz, tlim, t0);                      // the first child always exists
+    const bool h1 = slab_quantised(x01, y01, z01, 16, ax, ay, az, bx, by, bz, tlim, t1) && c1 != kEmptyChild;
+    const bool h2 = slab_quantised(x23, y23, z23, 0, ax, ay, az, bx, by, bz, tlim, t2) && c2 != kEmptyChild;
+    const bool h3 = slab_quantised(x23, y23, z23, 16, ax, ay, az, bx, by, bz, tlim, t3) && c3 != kEmptyChild;
     tested = 1u + (c1 != kEmptyChild ? 1u : 0u) + (c2 != kEmptyChild ? 1u : 0u) + (c3 != kEmptyChild ? 1u : 0u);
     const int nh = (h0 ? 1 : 0) + (h1 ? 1 : 0) + (h2 ? 1 : 0) + (h3 ? 1 : 0);
     if constexpr (ORDERED) {

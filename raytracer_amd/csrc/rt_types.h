@@ -63,9 +63,6 @@ static_assert(sizeof(Node128) == 128, "Node128 must be two 64-byte blocks");
 // child box always contains the exact one).  One 64-byte line, four dwordx4 loads instead of seven: the traversal kernels
 // keep a compute unit's vector-memory path busy 75-90 % of the time, and the tree takes half the cache.
 // Plane words: byte 0 / 1 = low / high plane of the first child of the pair, byte 2 / 3 = of the second.
-#ifndef RT_NODE_Q8
-#define RT_NODE_Q8 1
-#endif
 struct NodeQ64 {
     float origin[3];
     float sx;            // grid step per axis

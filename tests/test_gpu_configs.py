@@ -96,6 +96,41 @@ def test_c4_frame_from_the_square_sets_of_2_4_8_ranks_is_bit_identical():
             del d_all, frame
 
 
+@pytest.mark.parametrize("flatten", [True, False])
+@pytest.mark.parametrize("distance", [30.0, 300.0, 1200.0])
+def test_rays_from_far_away_find_what_a_search_without_boxes_finds(flatten, distance):
+    """Rays that start `distance` units outside the reduced cluster, aimed at points inside it.  The kernels' box tests only
+    prune, so the answer has to be the closest triangle of a search over all triangles without any box (the oracle's brute
+    force): beyond a few hundred units the rounding of a plain box test comes close to the 1e-4 the reference pads its boxes
+    with, and the waves take the widened box decode.  (Beyond about 1 600 units the fp32 triangle test itself answers for
+    rays that pass a triangle by more than that padding -- 2^-24 of the distance -- and no box test, the reference's
+    included, is conservative against it: that is the range the library supports.)"""
+    sc, cam_m, yfov = scenes.cluster_scene(38, 3, flatten=flatten)
+    S = oracle.OracleScene(sc)
+    rng = np.random.RandomState(7)
+    n = 3000
+    o0, d0 = primary(cam_m, yfov, 64, 48)
+    with api.Scene(sc) as g:
+        first = g.trace_rays(o0, d0)
+        hit = first["inst"] != abi.INVALID_ID
+        pts = (o0[hit] + d0[hit] * first["t"][hit][:, None]).astype(np.float64)      # points on the surfaces
+        target = pts[rng.randint(0, len(pts), n)]
+        dirs = rng.normal(size=(n, 3))
+        dirs /= np.linalg.norm(dirs, axis=1, keepdims=True)
+        o = (target - dirs * distance).astype(np.float32)
+        d = (target - o.astype(np.float64))
+        d = (d / np.linalg.norm(d, axis=1, keepdims=True)).astype(np.float32)
+        got = g.trace_rays(o, d)
+        brute, tied = S.brute_closest(o, d)
+        assert np.array_equal(brute["inst"] != abi.INVALID_ID, got["inst"] != abi.INVALID_ID)
+        assert np.array_equal(brute["prim"], got["prim"]) and np.array_equal(brute["inst"], got["inst"])
+        assert np.array_equal(brute["t"], got["t"])
+        assert (got["inst"] != abi.INVALID_ID).mean() > 0.5
+        tmax = np.where(np.isfinite(got["t"]), got["t"] * np.float32(1.0001), 1.0).astype(np.float32)
+        occ = g.test_visibility(o, d, tmax)
+        assert np.array_equal(occ != 0, got["inst"] != abi.INVALID_ID)
+
+
 def test_degenerate_triangle_nan_and_infinite_distances():
     """A triangle so small that its determinant is a denormal number makes Triangle::intersect (math/Triangle.h:34-101)
     divide by it: 1 / pDet overflows to infinity and t = p0Det * inf is +inf, or NaN when the ray starts in the triangle's

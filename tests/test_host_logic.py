@@ -122,3 +122,20 @@ def test_quantised_nodes_contain_the_exact_child_boxes(tmp_path, kind):
     r = subprocess.run([exe, "200000", str(kind + 1), str(kind)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok:")
+
+
+@pytest.mark.parametrize("distance", [1, 200, 10000, 1000000])
+def test_quantised_decode_never_rejects_a_box_a_ray_passes_through(tmp_path, distance):
+    """The kernels' box test on quantised nodes, restated on the host in fp32 (tests/native/check_quantised_decode.cpp): rays
+    aimed at corners, edges and faces of the child boxes of a tree over 20 000 boxes, from `distance` units away.  The widened
+    decode (taken when a wave holds a ray farther than 256 units from its tree, and by the instanced and per-lane walks)
+    accepts every ray that passes through the exact box at any distance; the plain decode accepts every ray through the
+    box without the reference's 1e-4 padding as long as the rays start within its range (checked for distance <= 240)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_qd")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-ffp-contract=off", "-pthread", "-I" + os.path.join(root, "raytracer_amd", "csrc"),
+                    "-I" + os.path.join(root, "include"), "-o", exe, os.path.join(root, "tests", "native", "check_quantised_decode.cpp")], check=True)
+    r = subprocess.run([exe, "20000", "3", str(distance)], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
