@@ -8,11 +8,13 @@ ranks (one process per GPU, scene replicated, strong scaling); every rank render
 and the buffers are gathered on rank 0 by the library's RCCL send / receive pairs inside the timed region.
 value = rays traced (primary + extension + shadow, every query counted once) by all ranks / wall time.
 
-At N = 1 the line also carries: the roofline of the dominant kernel (trace_stage_kernel: algorithmic bytes from a
-counting render / the stage's device time from a profiling render, both live), the CPU baseline (the oracle on a tile
-of the same frame) and, under "extras", the other configurations of BASELINE.json with a roofline each:
-configs[1] coherent primary rays and bounce rays on the blob, configs[2] the interior frame, configs[4] the
-49.8 M-triangle cluster.
+At N = 1 the line also carries: the roofline of the dominant kernel (trace_stage_kernel: the resource that binds it --
+VALU instruction issue -- from committed counters of this kernel over this run's live kernel time, beside the algorithmic
+bytes of a counting render against the L2 and HBM peaks), the CPU baseline (the oracle on a tile of the same frame) and,
+under "extras", the other configurations of BASELINE.json with a roofline each: configs[0] the scenegen scene's primary +
+shadow rays beside the oracle on the same rays, configs[1] coherent primary rays and bounce rays on the blob, configs[2]
+the interior frame, configs[3] the same interior at 3840x2160 and 256 spp on one GPU (the single-GPU reference of the
+2 / 4 / 8-GPU runs), configs[4] the 49.8 M-triangle cluster.
 
 Prints one JSON line (rank 0).
 """
@@ -31,6 +33,8 @@ sys.path.insert(0, HERE)
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak
 L2_PEAK_GBS = 34500.0   # aggregate L2 bandwidth of the 8 XCDs (MI355X_MICROARCH.md, "L2 (per XCD)")
 MALL_BYTES = 256 << 20  # Infinity Cache: scenes below this size are served on-die, HBM is not what binds them
+# VALU issue: a SIMD issues one wave64 vector instruction per 4 cycles; 256 CUs x 4 SIMDs x 2.4 GHz / 4
+VALU_PEAK_GINST = 256 * 4 * 2.4 / 4.0
 TILE = 32
 
 
@@ -41,35 +45,56 @@ def ray_bytes(rays, boxes, tris, out_bytes):
 
 
 def roofline(alg_bytes, kernel_ms, scene_bytes, kernel, extra=None):
-    """The traversal kernels' algorithmic bytes -- every child box and triangle a ray tests -- are what the L2 level has
-    to deliver to the compute units (the 32 KB L1 of a CU holds next to nothing of a tree): "achieved" is that rate
-    against the aggregate L2 bandwidth.  How much of it HBM had to deliver is a different, smaller number (the upper tree
-    levels are re-read from L2 and the Infinity Cache): `traffic` / `hbm` carry it when committed counters of the same
-    frame exist, `frac_of_hbm_peak` is the algorithmic rate against the HBM peak (above 1 for cache-resident scenes)."""
-    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
-    out = {"bound": "l2", "achieved": achieved, "peak": L2_PEAK_GBS, "unit": "GB/s", "frac": achieved / L2_PEAK_GBS,
+    """Roofline record of a traversal kernel from what this run measures: the algorithmic bytes (every child box and
+    triangle a ray tests when traversed on its own, 32 / 36 B each) over the kernel's time, against the HBM peak.  For scenes
+    that fit the caches that rate exceeds the HBM peak -- the tree is served by the compute units' L1s (79-84 % of the
+    look-ups), L2 and the Infinity Cache -- so it is a statement about the work done, not about a resource in use, and the
+    record says so (`algorithmic_GBps`, `frac_of_hbm_peak`, `frac_of_l2_peak`).  What actually binds these kernels is
+    vector-instruction issue; `attach_counters` replaces bound / achieved / peak / frac by that resource when committed
+    counters of this kernel on this workload exist, and adds the traffic the counters saw at each level."""
+    alg = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "achieved": alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / HBM_PEAK_GBS,
            "traffic": None, "kernel": kernel, "kernel_ms": kernel_ms, "algorithmic_bytes": alg_bytes,
-           "frac_of_hbm_peak": achieved / HBM_PEAK_GBS, "scene_bytes": scene_bytes,
-           "scene_fits_infinity_cache": bool(scene_bytes <= MALL_BYTES)}
+           "algorithmic_GBps": alg, "frac_of_hbm_peak": alg / HBM_PEAK_GBS, "frac_of_l2_peak": alg / L2_PEAK_GBS,
+           "scene_bytes": scene_bytes, "scene_fits_infinity_cache": bool(scene_bytes <= MALL_BYTES),
+           "note": "no committed counters for this kernel and workload: algorithmic bytes against the HBM peak (a fraction above 1 "
+                   "means the scene is served from the caches, not that HBM delivered it)"}
     if extra:
         out.update(extra)
     return out
 
 
 def attach_counters(rl, c, src, per):
-    """Quotes committed PMC figures (same kernel, same workload) beside a live roofline.  The counters belong to the build
-    the profile was taken from (its commit is in the summary file), the times beside them to this run."""
+    """Names the binding resource from committed PMC figures of the same kernel on the same workload.  The instruction count
+    of a frame (or launch) belongs to the kernel build and the workload, not to the run (the profile's commit is in the
+    summary file); the time it is divided by is this run's."""
+    label = "committed profile " + src + " (counters not measured in this run; kernel time measured in this run)"
     rl["traffic"] = c.get("hbm_bytes_per_" + per)
-    rl["counters"] = dict(c, source="committed profile " + src + " (not measured in this run)")
-    if c.get("valu_issue_frac"):
-        # what the counters show binding: the kernels issue VALU instructions in most of the issue slots there are
-        rl["binding"] = {"resource": "valu_issue", "frac": c["valu_issue_frac"], "waiting_share_of_wave_cycles": c.get("wait_any_share_of_wave_cycles"),
-                         "note": "SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x 2.4 GHz x kernel time), counters and time of the profiled run",
-                         "source": "committed profile " + src + " (not measured in this run)"}
-    if c.get("hbm_GBps"):
-        rl["hbm"] = {"GBps": c["hbm_GBps"], "frac_of_peak": c["hbm_GBps"] / HBM_PEAK_GBS, "l2_hit_rate": c.get("l2_hit_rate"),
-                     "note": "2 x FETCH_SIZE + WRITE_SIZE over the kernel's time; an upper bound for 16-byte gathers",
-                     "source": "committed profile " + src + " (not measured in this run)"}
+    rl["counters"] = dict(c, source=label)
+    seconds = rl["kernel_ms"] * 1e-3
+    if c.get("SQ_INSTS_VALU"):
+        ginst = c["SQ_INSTS_VALU"] / seconds / 1e9
+        rl.update({"bound": "valu_issue", "achieved": ginst, "peak": VALU_PEAK_GINST, "unit": "G wave64 VALU instructions/s",
+                   "frac": ginst / VALU_PEAK_GINST,
+                   "note": "SQ_INSTS_VALU of one %s (%s) / this run's kernel time, against 256 CUs x 4 SIMDs x 2.4 GHz / 4 cycles per "
+                           "instruction; frac in the profiled run itself: %.3f" % (per, label, c.get("valu_issue_frac", float("nan")))})
+        rl["binding"] = {"resource": "valu_issue", "frac": rl["frac"], "frac_in_profiled_run": c.get("valu_issue_frac"),
+                         "lanes_per_valu_instruction": c.get("lanes_per_valu_instruction"),
+                         "waiting_share_of_wave_cycles": c.get("wait_any_share_of_wave_cycles"), "source": label}
+    levels = {}
+    if c.get("l1_access_bytes"):
+        levels["l1"] = {"bytes": c["l1_access_bytes"], "GBps": c["l1_access_bytes"] / seconds / 1e9, "hit_rate": c.get("l1_hit_rate"),
+                        "note": "TCP_TOTAL_CACHE_ACCESSES x 64 B"}
+    if c.get("l2_to_cu_bytes"):
+        g = c["l2_to_cu_bytes"] / seconds / 1e9
+        levels["l2_to_cu"] = {"bytes": c["l2_to_cu_bytes"], "GBps": g, "frac_of_l2_peak": g / L2_PEAK_GBS, "l2_hit_rate": c.get("l2_hit_rate"),
+                              "note": "TCP_TCC_READ_REQ x 64 B: what the L1s asked L2 for"}
+    if c.get("hbm_bytes_per_" + per):
+        g = c["hbm_bytes_per_" + per] / seconds / 1e9
+        levels["hbm"] = {"bytes": c["hbm_bytes_per_" + per], "GBps": g, "frac_of_peak": g / HBM_PEAK_GBS,
+                         "note": "2 x FETCH_SIZE + WRITE_SIZE; an upper bound for 16-byte gathers"}
+    if levels:
+        rl["traffic_by_level"] = dict(levels, source=label)
 
 
 def committed_counters(tag):
@@ -225,6 +250,85 @@ def bench_headline(args, torch, dist, api, abi, scenes, rank, world, dev):
            # standing in for it ("fallback": such a line does not measure the library's RCCL exchange)
            "gather_kind": "native" if comm is not None else "fallback"}
     return res
+
+
+def bench_c1(args, torch, api, abi, scenes, dev):
+    """configs[0]: the scenegen.py scene (1 + 100 instances of a 960-triangle sphere mesh plus 16 analytic unit spheres, one
+    point light), 640x480, one primary ray per pixel and one shadow ray per hit towards the light (o = p + l * 1e-4,
+    tmax = |L - p|, material/NextEventEstimation.cpp:10-16).  The GPU beside the oracle on the very same rays; ids,
+    distances and occlusion flags are compared in the run."""
+    import oracle
+    W, H = 640, 480
+    sc, cam_m, yfov = scenes.c1_scene(seed=0)
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    scene = api.Scene(sc)
+    info = scene.info()
+    stream = torch.cuda.current_stream()
+    n = W * H
+    st = abi.make_settings(W, H, geometry_aa=1, material_aa=1, jitter_mode=abi.JITTER_CENTER)
+    d_o = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    d_d = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    api.generate_primary_device(cam, st, 0, d_o, d_d, stream)
+    hits = torch.empty((n, 5), dtype=torch.int32, device=dev)
+    cnt = torch.zeros((n, 2), dtype=torch.int32, device=dev)
+    scene.trace_counts_device(d_o, d_d, n, cnt, stream)
+    torch.cuda.synchronize()
+    boxes, tris = cnt.to(torch.float64).sum(dim=0).tolist()
+
+    def timed(f, reps=50):
+        for _ in range(3):
+            f()
+        torch.cuda.synchronize()
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(reps + 1)]
+        ev[0].record(stream)
+        for k in range(reps):
+            f()
+            ev[k + 1].record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean([ev[k].elapsed_time(ev[k + 1]) for k in range(reps)]))
+
+    ms_closest = timed(lambda: scene.trace_rays_device(d_o, d_d, n, hits, stream))
+    got = hits.cpu().numpy().view(abi.HIT_DTYPE).reshape(-1)
+    o, d = d_o.cpu().numpy(), d_d.cpu().numpy()
+    hit = got["inst"] != abi.INVALID_ID
+    light = np.asarray(sc.point_lights[0][0], dtype=np.float32)
+    hp = (o[hit] + d[hit] * got["t"][hit][:, None]).astype(np.float32)
+    to_l = light[None, :] - hp
+    lamp_t = np.linalg.norm(to_l, axis=1).astype(np.float32)
+    ldir = (to_l / np.maximum(lamp_t, 1e-20)[:, None]).astype(np.float32)
+    so = (hp + ldir * np.float32(0.0001)).astype(np.float32)
+    m = len(so)
+    s_o, s_d, s_t = torch.from_numpy(so).to(dev), torch.from_numpy(ldir).to(dev), torch.from_numpy(lamp_t).to(dev)
+    occ = torch.empty(m, dtype=torch.uint8, device=dev)
+    ms_any = timed(lambda: scene.test_visibility_device(s_o, s_d, s_t, m, occ, stream))
+    gpu_rate = (n + m) / (ms_closest + ms_any) / 1e3
+    # the oracle on the same rays, every host thread the box gives this process
+    threads = oracle.default_threads()
+    S = oracle.OracleScene(sc, threads=threads)
+    ref = S.trace_closest(o, d)
+    ref_occ = S.trace_any(so, ldir, lamp_t)
+    reps = 0
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 3.0:
+        S.trace_closest(o, d)
+        S.trace_any(so, ldir, lamp_t)
+        reps += 1
+    cpu_s = (time.perf_counter() - t0) / reps
+    same = bool(np.array_equal(ref["inst"], got["inst"]) and np.array_equal(ref["prim"], got["prim"]) and np.array_equal(ref["t"], got["t"])
+                and np.array_equal(ref_occ, occ.cpu().numpy()))
+    extra = {"kernel_ms_avg_per_launch": ms_closest, "boxes_per_ray": boxes / n, "tris_per_ray": tris / n,
+             "measured": "HIP events around each launch in this run",
+             "note": "a launch of 307 200 rays is 4 800 waves, fewer than the chip's 7 168 wave slots: its time is the walk of its slowest "
+                     "waves, no throughput roof is approached; algorithmic bytes against the HBM peak for the record"}
+    out = {"workload": "configs[0]: scenegen scene (%d mesh instances x 960 triangles + 16 analytic spheres), %dx%d, 1 primary ray per pixel + "
+                       "1 shadow ray per hit" % (len(sc.instances) - 16, W, H),
+           "mrays_per_s": gpu_rate, "primary_ms": ms_closest, "shadow_ms": ms_any, "primary_rays": n, "shadow_rays": m,
+           "identical_to_oracle": same,
+           "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms_closest, int(info.device_bytes), "trace_closest_kernel<true, false> (reference-order top level, one lane per ray)", extra),
+           "cpu_baseline": {"value": (n + m) / cpu_s / 1e6, "unit": "Mrays/s", "cores": threads, "kind": "port",
+                            "sample": "the same %d primary + %d shadow rays, %d repetitions in %.1f s" % (n, m, reps, cpu_s * reps)}}
+    scene.close()
+    return out
 
 
 def bench_c2(args, torch, api, abi, scenes, dev):
@@ -393,7 +497,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported beside the headline value")
     ap.add_argument("--no-c5", action="store_true", help="skip the 49.8 M-triangle configuration (about 40 s of scene set-up)")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--profile-tag", default="r02m", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
+    ap.add_argument("--profile-tag", default="r03", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
     args = ap.parse_args()
 
     import torch
@@ -430,10 +534,11 @@ def main():
         "value": mrays, "unit": "Mrays/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": res["elapsed"] / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
         "vs_baseline": None, "dtype": "f32", "data": "synthetic", "gather": res["gather_kind"],
-        "config": {"workload": "north-star: path-traced frame of the blob-in-a-room scene (%d triangles, diffuse + glossy, area + point light), "
-                               "%dx%d, %dx%d = %d spp, path length 9; %dx%d squares interleaved over %d GPU(s), gathered on rank 0"
-                               % (res["scene"].n_triangles(), st.width, st.height, st.geometry_aa, st.material_aa, st.geometry_aa * st.material_aa,
+        "config": {"workload": "north-star %dx%d, %dx%d = %d spp, path length 9: path-traced blob-in-a-room (%d triangles, diffuse + glossy, "
+                               "area + point light); %dx%d squares over %d GPU(s), gathered on rank 0"
+                               % (st.width, st.height, st.geometry_aa, st.material_aa, st.geometry_aa * st.material_aa, res["scene"].n_triangles(),
                                   TILE, TILE, world),
+                   "resolution": [st.width, st.height], "spp": st.geometry_aa * st.material_aa, "max_path_length": st.max_path_length,
                    "rays_per_frame": res["rays"] / args.steps, "ms_per_frame": res["elapsed"] / args.steps * 1e3,
                    "tree_nodes": int(info.n_nodes), "tree_max_depth": int(info.max_depth), "scene_build_ms": float(info.build_ms),
                    "scene_hbm_bytes": int(info.device_bytes), "gather": res["gather"], **res["checks"]},
@@ -460,10 +565,14 @@ def main():
     res["frame"] = None
     if rank == 0 and world == 1 and not args.no_extras:
         extras = {}
-        steps = [("configs[1]", lambda: bench_c2(args, torch, api, abi, scenes, dev)),
+        steps = [("configs[0]", lambda: bench_c1(args, torch, api, abi, scenes, dev)),
+                 ("configs[1]", lambda: bench_c2(args, torch, api, abi, scenes, dev)),
                  ("configs[2]", lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 1920, 1080, 8, 8, dev,
                                                     "configs[2]: interior scene, %d triangles, 1920x1080, 8x8 spp, path length 9",
-                                                    "trace_stage_kernel<kTraceSingle>"))]
+                                                    "trace_stage_kernel<kTraceSingle>")),
+                 ("configs[3]", lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 3840, 2160, 16, 16, dev,
+                                                    "configs[3] on one GPU: interior scene, %d triangles, 3840x2160, 16x16 = 256 spp, path length 9 (the "
+                                                    "single-GPU reference of the 2 / 4 / 8-GPU runs)", "trace_stage_kernel<kTraceSingle>", frames=1))]
         if not args.no_c5:
             steps.append(("configs[4]", lambda: bench_frame(torch, api, abi, *scenes.cluster_scene(38, args.subdiv, flatten=True), 1920, 1080, 4, 4, dev,
                                                             "configs[4]: 38 copies of the blob flattened into one mesh, %d triangles, camera inside the cluster, "
@@ -474,10 +583,12 @@ def main():
             except Exception as e:  # noqa: BLE001  (the headline line must still be printed)
                 extras[name] = {"error": "%s: %s" % (type(e).__name__, e)}
         counters, src = committed_counters(args.profile_tag)
-        c5 = extras.get("configs[4]", {})
-        if counters and "c5_trace_stage" in counters and "roofline" in c5 and args.subdiv == 8:
-            # the committed counters are of this very frame: the fabric traffic they show is what HBM actually had to deliver
-            attach_counters(c5["roofline"], counters["c5_trace_stage"], src, "frame")
+        # committed counters of these very frames (scripts/prof_c5.py, scripts/prof_interior.py render them with the same settings)
+        for name, key, ok in (("configs[4]", "c5_trace_stage", args.subdiv == 8), ("configs[2]", "interior_1080p_trace_stage", True),
+                              ("configs[3]", "interior_4k_trace_stage", True)):
+            e = extras.get(name, {})
+            if counters and key in counters and "roofline" in e and ok:
+                attach_counters(e["roofline"], counters[key], src, "frame")
         out["extras"] = extras
     if rank == 0:
         print(json.dumps(out))

@@ -47,6 +47,18 @@ def lib():
         L.orc_trace_closest.argtypes = [C.c_void_p, fp, fp, C.c_uint64, C.c_void_p, u32p, C.c_int]
         L.orc_trace_any.argtypes = [C.c_void_p, fp, fp, fp, C.c_uint64, u8p, C.c_int]
         L.orc_brute_closest.argtypes = [C.c_void_p, fp, fp, C.c_uint64, C.c_void_p, u32p, C.c_int]
+        L.orc_render_pixel_probe.restype = C.c_int64
+        L.orc_render_pixel_probe.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int, C.c_int, C.c_int64, C.c_int,
+                                             fp, C.POINTER(C.c_int)]
+        L.orc_attribute_pixel_to_libm.restype = C.c_int
+        L.orc_attribute_pixel_to_libm.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int, C.c_int, fp, C.c_float, C.c_float,
+                                                  C.POINTER(C.c_int64), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        L.orc_scene_set_gather_rule.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_set_gather_rule.restype = None
+        L.orc_scene_set_closest_rule.argtypes = [C.c_void_p, C.c_int]
+        L.orc_scene_set_closest_rule.restype = None
+        L.orc_scene_set_primary_rays.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_scene_set_primary_rays.restype = None
         L.orc_ray_hits_instance_box.argtypes = [C.c_void_p, fp, fp, C.c_uint64, C.c_uint32, u8p]
         L.orc_generate_primary.argtypes = [C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), C.c_int32, fp, fp]
         L.orc_render.argtypes = [C.c_void_p, C.POINTER(abi.Camera), C.POINTER(abi.RenderSettings), fp,
@@ -161,6 +173,49 @@ class OracleScene:
         lib().orc_gather_photons(self._h, p.ctypes.data_as(C.c_void_p), d.ctypes.data_as(C.c_void_p), len(p),
                                  out.ctypes.data_as(C.c_void_p), threads or self.threads)
         return out
+
+    def set_closest_rule(self, rule: int):
+        """0: the reference's tree walk (default).  1: the closest hit by the tree-independent definition the GPU kernels
+        implement (smallest t over all primitives; equal t -> the smaller (instance, triangle)), by a search without boxes.
+        A test hook: it shows that a difference comes from an exact-distance tie, where the reference's pick depends on
+        its tree."""
+        lib().orc_scene_set_closest_rule(self._h, int(rule))
+
+    def set_gather_rule(self, rule: int):
+        """0: the reference's photon search (compares rounded square roots; default).  1: the 20 nearest accepted photons by
+        squared distance, every photon looked at -- the set an exact search finds.  A test hook: it shows that a difference
+        comes from photons that tie for the 20th place once their distances are rounded."""
+        lib().orc_scene_set_gather_rule(self._h, int(rule))
+
+    def set_primary_rays(self, origins=None, dirs=None):
+        """Camera rays for later renders from arrays shaped (geometry_aa, height, width, 3) instead of the oracle's own
+        camera (None restores it).  A test hook: it shows that a difference comes from the camera rays' last bits."""
+        if origins is None:
+            self._primary = None
+            lib().orc_scene_set_primary_rays(self._h, None, None)
+            return
+        o, d = np.ascontiguousarray(origins, dtype=np.float32), np.ascontiguousarray(dirs, dtype=np.float32)
+        assert o.shape == d.shape and o.ndim == 4 and o.shape[3] == 3
+        self._primary = (o, d)      # kept alive while the scene uses them
+        lib().orc_scene_set_primary_rays(self._h, o.ctypes.data, d.ctypes.data)
+
+    LIBM_NAMES = ("acos", "asin", "atan2", "tan", "sin", "cos", "pow")
+
+    def render_pixel_probe(self, cam, st, x, y, target=-1, ulps=0):
+        """Pixel (x, y) with the result of its `target`-th libm call moved by `ulps` units in the last place: (rgb, number of
+        libm calls the pixel made)."""
+        rgb = np.zeros(3, dtype=np.float32)
+        n = lib().orc_render_pixel_probe(self._h, C.byref(cam), C.byref(st), int(x), int(y), int(target), int(ulps), _fp(rgb), None)
+        return rgb, int(n)
+
+    def attribute_pixel_to_libm(self, cam, st, x, y, want, tol_rel=1e-4, floor=0.0):
+        """Looks for one libm call of pixel (x, y) whose result, moved by one unit in the last place, turns the oracle's pixel
+        into `want`: (call index, +1 / -1, function name) or None."""
+        w = np.ascontiguousarray(want, dtype=np.float32)
+        call, ulps, fn = C.c_int64(), C.c_int(), C.c_int()
+        ok = lib().orc_attribute_pixel_to_libm(self._h, C.byref(cam), C.byref(st), int(x), int(y), _fp(w), float(tol_rel), float(floor),
+                                               C.byref(call), C.byref(ulps), C.byref(fn))
+        return (int(call.value), int(ulps.value), self.LIBM_NAMES[fn.value] if 0 <= fn.value < len(self.LIBM_NAMES) else "?") if ok else None
 
     def render(self, cam: abi.Camera, st: abi.RenderSettings, threads=None):
         img = np.zeros((st.height, st.width, 3), dtype=np.float32)

@@ -635,6 +635,19 @@ struct orc_scene {
     std::vector<KdNode> kd;
     int32_t kdRoot = -1;
     int pmMode = RTGPU_PM_NONE, pmDepth = 0;
+    // Test hooks (orc_scene_set_closest_rule / orc_scene_set_primary_rays): they let a test show that a pixel in which the
+    // GPU and the reference's walk differ is one of the documented cases.
+    //   closestRule 1: closest hits by the tree-independent definition the GPU kernels implement -- the smallest t over all
+    //   primitives, equal t -> the smaller (instance, triangle) -- instead of the reference's walk, whose pick among
+    //   exactly tied hits depends on its tree;
+    //   primaryO / primaryD: camera rays taken from these arrays ([sample][y][x][3]) instead of camera_ray().
+    int closestRule = 0;
+    //   gatherRule 1: the k nearest accepted photons by squared distance (strict <, every photon looked at) instead of the
+    //   reference's walk, which compares rounded square roots: photons whose distances differ by less than that rounding
+    //   count as tied there, and which of them ends up in the list follows from the walk.
+    int gatherRule = 0;
+    const float* primaryO = nullptr;
+    const float* primaryD = nullptr;
 };
 
 namespace {
@@ -714,42 +727,83 @@ V3 mesh_tangent(const Mesh& m, uint32_t tri)
     return V3{(i00 * d0.x) + (i01 * d1.x), (i00 * d0.y) + (i01 * d1.y), (i00 * d0.z) + (i01 * d1.z)};
 }
 
-// Scene::traceRay, scene/renderable/Scene.cpp:14-17
-SceneHit scene_trace(const orc_scene& S, V3 o, V3 d)
+// What Scene::traceRay returns for the hit (instance instIdx, triangle `tri` of its mesh or a sphere) at distance t.
+SceneHit finish_hit(const orc_scene& S, V3 o, V3 d, uint32_t instPos, uint32_t instIdx, uint32_t tri, double t, float beta, float gamma, V3 sphereNormal)
 {
-    InstHit ih = bvh_trace<InstHit>(S.topNodes, 0, o, d, [&](uint32_t b, uint32_t e) { return instances_trace(S, b, e, o, d); });
-    SceneHit r;
-    if (!ih.ok) return r;
-    const uint32_t instIdx = S.instOrder[ih.instPos];
     const Instance& in = S.instances[instIdx];
+    SceneHit r;
     r.ok = true;
-    r.ro = o; r.rd = d; r.t = ih.t;
-    r.instPos = ih.instPos;
+    r.ro = o; r.rd = d; r.t = t;
+    r.instPos = instPos;
     r.inst = instIdx;
-    r.beta = ih.beta; r.gamma = ih.gamma;
+    r.beta = beta; r.gamma = gamma;
     V3 objN;
     if (in.shape >= 0) {
         const Mesh& m = S.meshes[in.shape];
-        uint32_t tri = m.order[ih.pos];
         r.prim = tri;
         // normal interpolation, shape/TriangleMesh.cpp:114-120
-        float alfa = 1.0f - ih.beta - ih.gamma;
+        float alfa = 1.0f - beta - gamma;
         V3 na = m.normals[m.indices[3 * tri]], nb = m.normals[m.indices[3 * tri + 1]], nc = m.normals[m.indices[3 * tri + 2]];
-        objN = ((alfa * na) + (ih.beta * nb)) + (ih.gamma * nc);
+        objN = ((alfa * na) + (beta * nb)) + (gamma * nc);
         if (!m.texCoords.empty()) { // shape/TriangleMesh.cpp:122-128; (0, 0) otherwise (:143-146)
             const float* ta = &m.texCoords[2 * m.indices[3 * tri]];
             const float* tb = &m.texCoords[2 * m.indices[3 * tri + 1]];
             const float* tc = &m.texCoords[2 * m.indices[3 * tri + 2]];
-            r.u = ((alfa * ta[0]) + (ih.beta * tb[0])) + (ih.gamma * tc[0]);
-            r.v = ((alfa * ta[1]) + (ih.beta * tb[1])) + (ih.gamma * tc[1]);
+            r.u = ((alfa * ta[0]) + (beta * tb[0])) + (gamma * tc[0]);
+            r.v = ((alfa * ta[1]) + (beta * tb[1])) + (gamma * tc[1]);
         }
         r.tangent = xf_vector(in.xf.m, mesh_tangent(m, tri)); // InstancedModelList.cpp:131
     } else {
         r.prim = RTGPU_INVALID_ID;
-        objN = ih.objNormal;
+        objN = sphereNormal;
     }
     r.normal = normalized(xf_normal(in.xf.inv, objN)); // InstancedModelList.cpp:129-130
     return r;
+}
+
+// closestRule 1 (test hook): every primitive tested, first met in (instance, triangle) order wins among equal distances
+SceneHit scene_trace_all(const orc_scene& S, V3 o, V3 d)
+{
+    double bestT = INFINITY;
+    bool ok = false;
+    uint32_t bestInst = 0, bestTri = RTGPU_INVALID_ID;
+    float bestBeta = 0, bestGamma = 0;
+    V3 bestN{};
+    for (uint32_t ii = 0; ii < S.instances.size(); ++ii) {
+        const Instance& in = S.instances[ii];
+        V3 to = xf_point(in.xf.inv, o), td = xf_vector(in.xf.inv, d);
+        if (in.shape >= 0) {
+            const Mesh& m = S.meshes[in.shape];
+            for (uint32_t tri = 0; tri < m.ntri; ++tri) {
+                float be, ga;
+                double t;
+                if (!tri_intersect(to, td, m.vertices[m.indices[3 * tri]], m.vertices[m.indices[3 * tri + 1]], m.vertices[m.indices[3 * tri + 2]], be, ga, t)) continue;
+                if (!ok || t < bestT) { ok = true; bestT = t; bestInst = ii; bestTri = tri; bestBeta = be; bestGamma = ga; }
+            }
+        } else {
+            double t;
+            if (sphere_intersect(to, td, t) && (!ok || t < bestT)) {
+                ok = true; bestT = t; bestInst = ii; bestTri = RTGPU_INVALID_ID; bestBeta = 0; bestGamma = 0;
+                bestN = to + ((float)t * td);
+            }
+        }
+    }
+    if (!ok) return SceneHit{};
+    uint32_t pos = 0;
+    for (uint32_t k = 0; k < S.instOrder.size(); ++k) if (S.instOrder[k] == bestInst) pos = k;
+    return finish_hit(S, o, d, pos, bestInst, bestTri, bestT, bestBeta, bestGamma, bestN);
+}
+
+// Scene::traceRay, scene/renderable/Scene.cpp:14-17
+SceneHit scene_trace(const orc_scene& S, V3 o, V3 d)
+{
+    if (S.closestRule == 1) return scene_trace_all(S, o, d);
+    InstHit ih = bvh_trace<InstHit>(S.topNodes, 0, o, d, [&](uint32_t b, uint32_t e) { return instances_trace(S, b, e, o, d); });
+    if (!ih.ok) return SceneHit{};
+    const uint32_t instIdx = S.instOrder[ih.instPos];
+    const Instance& in = S.instances[instIdx];
+    const uint32_t tri = in.shape >= 0 ? S.meshes[in.shape].order[ih.pos] : RTGPU_INVALID_ID;
+    return finish_hit(S, o, d, ih.instPos, instIdx, tri, ih.t, ih.beta, ih.gamma, ih.objNormal);
 }
 
 // Scene::testVisibility, scene/renderable/Scene.cpp:19-22
@@ -757,6 +811,41 @@ bool scene_visibility(const orc_scene& S, V3 o, V3 d, float maxT)
 {
     return bvh_visibility(S.topNodes, 0, o, d, maxT, [&](uint32_t b, uint32_t e) { return instances_visibility(S, b, e, o, d, maxT); });
 }
+
+// ------------------------------------------------------------------------------------------
+// The render path's calls into libm (transcendental functions: glibc here, the device's math library on the GPU; both are
+// accurate to the last bit or so, neither is correctly rounded, so now and then their results differ in that bit).
+// Test hook: the result of the `target`-th call of a pixel's evaluation can be moved by `ulps` units in the last place
+// (orc_render_pixel_probe, orc_attribute_pixel_to_libm) -- which shows whether a pixel sits on a branch that such a
+// last-bit difference flips.  Square roots and divisions are correctly rounded on both sides and are not counted.
+// ------------------------------------------------------------------------------------------
+struct LibmProbe { long target = -1; int ulps = 0; long calls = 0; int fn = -1; };
+thread_local LibmProbe g_libm;
+enum { LM_ACOS = 0, LM_ASIN, LM_ATAN2, LM_TAN, LM_SIN, LM_COS, LM_POW };
+template <typename T>
+inline T libm_result(T v, int fn)
+{
+    if (g_libm.calls++ == g_libm.target) {
+        g_libm.fn = fn;
+        for (int k = 0; k < std::abs(g_libm.ulps); ++k) v = std::nextafter(v, g_libm.ulps > 0 ? (T)INFINITY : (T)-INFINITY);
+    }
+    return v;
+}
+inline double lm_acos(double x) { return libm_result(std::acos(x), LM_ACOS); }
+inline float lm_acos(float x) { return libm_result(std::acos(x), LM_ACOS); }
+inline double lm_asin(double x) { return libm_result(std::asin(x), LM_ASIN); }
+inline float lm_asin(float x) { return libm_result(std::asin(x), LM_ASIN); }
+inline double lm_atan2(double y, double x) { return libm_result(std::atan2(y, x), LM_ATAN2); }
+inline float lm_atan2(float y, float x) { return libm_result(std::atan2(y, x), LM_ATAN2); }
+inline double lm_tan(double x) { return libm_result(std::tan(x), LM_TAN); }
+inline float lm_tan(float x) { return libm_result(std::tan(x), LM_TAN); }
+inline double lm_sin(double x) { return libm_result(std::sin(x), LM_SIN); }
+inline float lm_sin(float x) { return libm_result(std::sin(x), LM_SIN); }
+inline double lm_cos(double x) { return libm_result(std::cos(x), LM_COS); }
+inline float lm_cos(float x) { return libm_result(std::cos(x), LM_COS); }
+inline double lm_pow(double x, double y) { return libm_result(std::pow(x, y), LM_POW); }
+inline float lm_pow(float x, float y) { return libm_result(std::pow(x, y), LM_POW); }
+inline double lm_pow(float x, double y) { return libm_result(std::pow((double)x, y), LM_POW); }
 
 // ------------------------------------------------------------------------------------------
 // Counter-based RNG shared with the HIP integrator (replaces math/FastRandom.h)
@@ -830,11 +919,11 @@ inline Basis basis_from2(V3 a, V3 b2)
 // mapSampleToCosineWeightedHemisphere, math/Sampler.h:51-59 (radius 1, exponent 1)
 inline V3 cosine_hemisphere(float r1, float r2)
 {
-    float cos_theta = std::pow(r1, 1.0f / (1.0f + 1.0f));
+    float cos_theta = lm_pow(r1, 1.0f / (1.0f + 1.0f));
     float sin_theta = std::sqrt(1.0f - cos_theta * cos_theta);
     double phi = 2.0f * PI * r2;
-    double cos_phi = std::cos(phi);
-    double sin_phi = std::sin(phi);
+    double cos_phi = lm_cos(phi);
+    double sin_phi = lm_sin(phi);
     return V3{(float)(1.0f * sin_theta * cos_phi), (float)(1.0f * sin_theta * sin_phi), 1.0f * cos_theta};
 }
 
@@ -844,11 +933,11 @@ inline void sampleP22(double theta_i, double U1, double U2, float& sx, float& sy
     if (theta_i < 0.0001) {
         const double r = std::sqrt(U1 / (1 - U1));
         const double phi = 6.28318530718 * U2;
-        sx = (float)(r * std::cos(phi));
-        sy = (float)(r * std::sin(phi));
+        sx = (float)(r * lm_cos(phi));
+        sy = (float)(r * lm_sin(phi));
         return;
     }
-    const double tan_theta_i = std::tan(theta_i);
+    const double tan_theta_i = lm_tan(theta_i);
     const double a = 1 / (tan_theta_i);
     const double G1 = 2 / (1 + std::sqrt(1.0 + 1.0 / (a * a)));
     const double A = 2.0 * U1 / G1 - 1.0;
@@ -875,13 +964,13 @@ inline V3 vndf_sample(V3 smoothNormal, V3 worldIncoming, float roughness, double
     V3 st = normalized(V3{incoming.x * roughness, incoming.y * roughness, incoming.z});
     float theta = 0.0, phi = 0.0;
     if (st.z < 0.99999) {
-        theta = std::acos(st.z);
-        phi = std::atan2(st.y, st.x);
+        theta = lm_acos(st.z);
+        phi = lm_atan2(st.y, st.x);
     }
     float slx, sly;
     sampleP22(theta, rand1, rand2, slx, sly);
-    float rx = std::cos(phi) * slx - std::sin(phi) * sly;
-    float ry = std::sin(phi) * slx + std::cos(phi) * sly;
+    float rx = lm_cos(phi) * slx - lm_sin(phi) * sly;
+    float ry = lm_sin(phi) * slx + lm_cos(phi) * sly;
     rx *= roughness;
     ry *= roughness;
     V3 micro = normalized(V3{-rx, -ry, 1.0f});
@@ -894,9 +983,9 @@ inline V3 vndf_sample(V3 smoothNormal, V3 worldIncoming, float roughness, double
 // ---- GGX terms, material/GlossyMaterial.cpp:27-66 -----------------------------------------
 inline float ggx_g1(float roughness, V3 v, V3 n, V3 m)
 {
-    float theta_v = std::acos(dot(v, n));
+    float theta_v = lm_acos(dot(v, n));
     if (dot(v, m) / dot(v, n) > 0.0f) {
-        float tan_theta = std::tan(theta_v);
+        float tan_theta = lm_tan(theta_v);
         return 2.0f / (1.0f + std::sqrt(1.0f + (roughness * roughness) * (tan_theta * tan_theta)));
     }
     return 0.0f;
@@ -907,10 +996,10 @@ inline float ggx_brdf(float roughness, V3 i, V3 o, V3 n, V3 m)
     if (g == 0.0f) return 0.0f;
     float d = 0.0f;
     if (dot(m, n) > 0) {
-        float theta_m = std::acos(dot(m, n));
+        float theta_m = lm_acos(dot(m, n));
         float aSqr = roughness * roughness;
-        float tan_theta_m = std::tan(theta_m);
-        float cos_theta_m = std::cos(theta_m);
+        float tan_theta_m = lm_tan(theta_m);
+        float cos_theta_m = lm_cos(theta_m);
         float cos_theta_m_sqr = cos_theta_m * cos_theta_m;
         float x = aSqr + tan_theta_m * tan_theta_m;
         d = aSqr / ((float)M_PI * cos_theta_m_sqr * cos_theta_m_sqr * x * x);
@@ -993,7 +1082,7 @@ V3 sample_steradian_sphere(V3 center, float angle, float r0, float r1)
 {
     float alpha = (r0 - 0.5f) * 2.0f * angle;
     float beta = (r1 - 0.5f) * 2.0f * angle;
-    double sa = std::sin((double)alpha), ca = std::cos((double)alpha), sb = std::sin((double)beta), cb = std::cos((double)beta);
+    double sa = lm_sin((double)alpha), ca = lm_cos((double)alpha), sb = lm_sin((double)beta), cb = lm_cos((double)beta);
     V3 l{(float)sb, (float)(-sa * cb), (float)(ca * cb)};
     Basis basis = basis_from(center);
     return V3{basis.u.x * l.x + (basis.v.x * l.y + basis.w.x * l.z),
@@ -1146,6 +1235,24 @@ struct Gather { // the state of one KDTree::getElementsNearestTo call
 rtgpu_photon_gather gather_photons(const orc_scene& S, V3 target, V3 dir, unsigned k = 20)
 {
     rtgpu_photon_gather out{};
+    if (S.gatherRule == 1) {   // test hook, see orc_scene
+        std::vector<std::pair<float, uint32_t>> best;   // (squared distance, photon), kept sorted, at most k
+        for (uint32_t i = 0; i < S.photons.size(); ++i) {
+            if (!(dot(dir, mk(S.photons[i].normal)) >= 0)) continue;
+            const V3 diff = mk(S.photons[i].pos) - target;
+            const float d2 = dot(diff, diff);
+            if (best.size() == k && !(d2 < best.back().first)) continue;
+            auto it = std::upper_bound(best.begin(), best.end(), std::make_pair(d2, 0xFFFFFFFFu));
+            best.insert(it, std::make_pair(d2, i));
+            if (best.size() > k) best.pop_back();
+        }
+        out.count = (uint32_t)best.size();
+        out.max_dist = best.size() == k ? std::sqrt(best.back().first) : (best.empty() ? 1E9f : std::numeric_limits<float>::max());
+        RGBf value;
+        for (const auto& b : best) value = rgb_add(value, RGBf{S.photons[b.second].energy[0], S.photons[b.second].energy[1], S.photons[b.second].energy[2]});
+        out.energy[0] = value.r; out.energy[1] = value.g; out.energy[2] = value.b;
+        return out;
+    }
     float searchRadius = 1E9;
     unsigned found = 0;
     Gather g{S, target, dir, k, std::vector<int64_t>(k, -1)};
@@ -1294,7 +1401,7 @@ RGBf texture_get(const orc_scene::Tex& T, float x, float y)
     py = std::min(py, T.height - 1);
     size_t offset = ((size_t)py * T.width + px) * 4;
     RGBf color{(float)T.rgba[offset] / 255.0f, (float)T.rgba[offset + 1] / 255.0f, (float)T.rgba[offset + 2] / 255.0f};
-    return RGBf{(float)std::pow(color.r, T.gamma), (float)std::pow(color.g, T.gamma), (float)std::pow(color.b, T.gamma)}; // RGB::pow(double)
+    return RGBf{(float)lm_pow(color.r, T.gamma), (float)lm_pow(color.g, T.gamma), (float)lm_pow(color.b, T.gamma)}; // RGB::pow(double)
 }
 
 // sample_normal_map, material/NormalMapSampler.h:7-21 with Transformation::tangentToObject (math/Transformation.cpp:132-145)
@@ -1607,7 +1714,7 @@ RGBf leaf_bsdf(const orc_scene& S, const TransportNode& tn, uint32_t mi, RGBf in
         if (isInternalRay) {
             double t = std::isnan(meta.t) ? tn.hit.t : (double)meta.t;
             double power = m.roughness * t;   // attenuationStrength (float) * t
-            val = rgb_mul(val, RGBf{(float)std::pow(m.color[0], power), (float)std::pow(m.color[1], power), (float)std::pow(m.color[2], power)});
+            val = rgb_mul(val, RGBf{(float)lm_pow(m.color[0], power), (float)lm_pow(m.color[1], power), (float)lm_pow(m.color[2], power)});
         }
         return val;
     }
@@ -1706,9 +1813,9 @@ RGBf env_radiance(const orc_scene& S, V3 dir)
         return rgb_add(rgb_scale_f(RGBf{0.5f, 0.7f, 1.0f}, t), rgb_scale_f(RGBf{1.0f, 1.0f, 1.0f}, 1.0f - t));
     }
     if (S.hasEnv != 2) return S.envRadiance;
-    const float latitude = std::asin(dir.y);
-    const float cl = std::cos(latitude);
-    const double longitude = M_PI + std::atan2(dir.z / cl, dir.x / cl);
+    const float latitude = lm_asin(dir.y);
+    const float cl = lm_cos(latitude);
+    const double longitude = M_PI + lm_atan2(dir.z / cl, dir.x / cl);
     const double x = S.envW * longitude / (2.0f * M_PI);
     const double y = S.envH * (1.0f - (((M_PI / 2.0f) + latitude) / M_PI));
     int xi = x == x ? (int)x : 0, yi = y == y ? (int)y : 0;
@@ -1735,7 +1842,7 @@ RGBf path_energy(const orc_scene& S, const std::vector<TransportNode>& path)
 // sampleUniformStratifiedCube, math/Sampler.h:28-41
 V3 stratified_cube(float level, float sampleI, V3 r)
 {
-    float binsPerAxis = std::pow(level, 1.0f / 3.0f);
+    float binsPerAxis = lm_pow(level, 1.0f / 3.0f);
     float oneOverBinsPerAxis = 1.0f / binsPerAxis;
     float binX = std::fmod(sampleI, binsPerAxis);
     float binY = std::floor(std::fmod(sampleI, binsPerAxis * binsPerAxis) * oneOverBinsPerAxis);
@@ -1750,8 +1857,8 @@ void uniform_circle(float radius, V3 r, float& x, float& y)
     float angle = r.x * 2.0f * M_PI;
     float dist = (r.y * radius) + (r.z * radius);
     if (dist > radius) dist = (2.0f * radius) - dist;
-    x = std::cos(angle) * dist;
-    y = std::sin(angle) * dist;
+    x = lm_cos(angle) * dist;
+    y = lm_sin(angle) * dist;
 }
 
 // PerspectiveCamera::generateRay, camera/PerspectiveCamera.cpp:26-52
@@ -1800,6 +1907,10 @@ RGBf render_pixel(RenderCtx& R, const rtgpu_camera& cam, const rtgpu_render_sett
         RandCtx camRc{st.seed, pixel, (uint32_t)(i * M), VERTEX_CAMERA};
         V3 ro, rd;
         camera_ray(cam, x, y, st.width, st.height, G, i, st.jitter_mode, camRc, ro, rd);
+        if (S.primaryO && S.primaryD) {   // test hook: the camera rays another implementation generated
+            const size_t k = (((size_t)i * st.height + y) * st.width + x) * 3;
+            ro = mk(S.primaryO + k); rd = mk(S.primaryD + k);
+        }
         R.primary++;
         SceneHit hit = scene_trace(S, ro, rd);
         path.clear();
@@ -2144,6 +2255,52 @@ void orc_brute_closest(const orc_scene* s, const float* o, const float* d, uint6
             if (n_tied) n_tied[i] = tied;
         }
     });
+}
+
+// Test hooks, see orc_scene.  The arrays of orc_scene_set_primary_rays stay the caller's and must outlive the renders
+// that use them; null pointers restore camera_ray().
+void orc_scene_set_closest_rule(orc_scene* s, int rule) { s->closestRule = rule; }
+void orc_scene_set_gather_rule(orc_scene* s, int rule) { s->gatherRule = rule; }
+void orc_scene_set_primary_rays(orc_scene* s, const float* o, const float* d) { s->primaryO = o; s->primaryD = d; }
+
+// Test hooks on the render path's libm calls (see LibmProbe).  orc_render_pixel_probe renders pixel (x, y) on the calling
+// thread with the result of its `target`-th libm call moved by `ulps` units in the last place (target < 0: nothing moved)
+// and returns the number of libm calls the pixel made; *fn receives which function the moved call was (LM_*), -1 if none.
+int64_t orc_render_pixel_probe(const orc_scene* s, const rtgpu_camera* cam, const rtgpu_render_settings* st, int x, int y, int64_t target, int ulps,
+                               float rgb[3], int* fn)
+{
+    g_libm = LibmProbe{(long)target, ulps, 0, -1};
+    RenderCtx R{*s, nullptr};
+    const RGBf p = render_pixel(R, *cam, *st, x, y);
+    rgb[0] = p.r; rgb[1] = p.g; rgb[2] = p.b;
+    const int64_t n = g_libm.calls;
+    if (fn) *fn = g_libm.fn;
+    g_libm = LibmProbe{};
+    return n;
+}
+
+// Looks for ONE libm call of pixel (x, y) whose result, moved by one or two units in the last place either way, turns the pixel
+// into `want` (every channel within tol_rel of the larger of the pixel's brightest channel and `floor`).  Returns 1 and the
+// call / direction / function when there is one, 0 otherwise.
+int orc_attribute_pixel_to_libm(const orc_scene* s, const rtgpu_camera* cam, const rtgpu_render_settings* st, int x, int y, const float want[3],
+                                float tol_rel, float floor, int64_t* call, int* ulps, int* fn)
+{
+    float rgb[3];
+    const int64_t n = orc_render_pixel_probe(s, cam, st, x, y, -1, 0, rgb, nullptr);
+    const float scale = std::max(std::max(want[0], std::max(want[1], want[2])), floor);
+    static const int kMoves[4] = {1, -1, 2, -2};
+    for (int64_t k = 0; k < n; ++k)
+        for (int u : kMoves) {
+            int f = -1;
+            orc_render_pixel_probe(s, cam, st, x, y, k, u, rgb, &f);
+            if (std::fabs(rgb[0] - want[0]) <= tol_rel * scale && std::fabs(rgb[1] - want[1]) <= tol_rel * scale && std::fabs(rgb[2] - want[2]) <= tol_rel * scale) {
+                if (call) *call = k;
+                if (ulps) *ulps = u;
+                if (fn) *fn = f;
+                return 1;
+            }
+        }
+    return 0;
 }
 
 void orc_ray_hits_instance_box(const orc_scene* s, const float* o, const float* d, uint64_t n, uint32_t inst, uint8_t* out)

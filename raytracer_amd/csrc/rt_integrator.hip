@@ -49,6 +49,9 @@
 #define RT_SHADE_BLOCK 256
 #endif
 
+#ifndef RT_TRACE_WAVES
+#define RT_TRACE_WAVES 7
+#endif
 namespace rt {
 
 namespace {
@@ -1074,7 +1077,7 @@ __device__ __forceinline__ void extend_block(const SceneView& sv, const Pool& po
 }
 
 template <int MODE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == kTraceInstances ? 6 : (MODE == kTraceSingle ? 7 : 1)))) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, const uint32_t* __restrict__ cnt)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == kTraceInstances ? 6 : (MODE == kTraceSingle ? RT_TRACE_WAVES : 1)))) void trace_stage_kernel(SceneView sv, Pool pool, const uint32_t* __restrict__ extQueue, const uint32_t* __restrict__ cnt)
 {
     __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;

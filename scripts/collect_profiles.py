@@ -7,6 +7,8 @@ live numbers.
 HBM bytes = 2 x FETCH_SIZE + WRITE_SIZE (both in KiB): on gfx950 FETCH_SIZE tallies 128-B requests at 64 B, WRITE_SIZE
 is exact.  The x2 is calibrated for wide streaming reads; for these kernels' 16-B gathers it is an upper bound.
 VALU issue share = SQ_INSTS_VALU x 4 cycles / (1024 SIMDs x kernel time x 2.4 GHz).
+Lanes per VALU instruction = SQ_THREAD_CYCLES_VALU / SQ_ACTIVE_INST_VALU.  L2 -> compute-unit traffic = TCP_TCC_READ_REQ x 64 B
+(the L1s' read requests to L2), L1 accesses = TCP_TOTAL_CACHE_ACCESSES (64-byte look-ups).
 """
 import collections
 import csv
@@ -54,9 +56,22 @@ def derived(c, seconds):
             o["hbm_GBps"] = o["hbm_bytes"] / seconds / 1e9
     if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
         o["l2_hit_rate"] = c["TCC_HIT_sum"] / max(1.0, c["TCC_HIT_sum"] + c["TCC_MISS_sum"])
-    for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY"):
+    for k in ("SQ_WAVES", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_ANY",
+              "SQ_THREAD_CYCLES_VALU", "SQ_ACTIVE_INST_VALU", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR",
+              "TCP_TCC_READ_REQ_sum", "TCP_TOTAL_CACHE_ACCESSES_sum", "TCP_PENDING_STALL_CYCLES_sum", "TA_TA_BUSY_sum"):
         if k in c:
             o[k] = c[k]
+    if "SQ_THREAD_CYCLES_VALU" in c and c.get("SQ_ACTIVE_INST_VALU"):
+        o["lanes_per_valu_instruction"] = c["SQ_THREAD_CYCLES_VALU"] / c["SQ_ACTIVE_INST_VALU"]
+    if "TCP_TCC_READ_REQ_sum" in c:
+        o["l2_to_cu_bytes"] = c["TCP_TCC_READ_REQ_sum"] * 64.0
+        if seconds:
+            o["l2_to_cu_GBps"] = o["l2_to_cu_bytes"] / seconds / 1e9
+        if c.get("TCP_TOTAL_CACHE_ACCESSES_sum"):
+            o["l1_hit_rate"] = 1.0 - c["TCP_TCC_READ_REQ_sum"] / c["TCP_TOTAL_CACHE_ACCESSES_sum"]
+            o["l1_access_bytes"] = c["TCP_TOTAL_CACHE_ACCESSES_sum"] * 64.0
+    if "TA_TA_BUSY_sum" in c and seconds:
+        o["ta_busy_share"] = c["TA_TA_BUSY_sum"] / 256.0 / (seconds * 2.4e9)   # per compute unit, against the kernel's cycles at 2.4 GHz
     if "SQ_INSTS_VALU" in c and seconds:
         o["valu_issue_frac"] = c["SQ_INSTS_VALU"] * 4.0 / 1024.0 / (seconds * 2.4e9)
     if "SQ_WAIT_ANY" in c and "SQ_WAVE_CYCLES" in c:
@@ -114,6 +129,22 @@ def main():
                 e["hbm_bytes_per_frame"] = e.pop("hbm_bytes")
         summary["c5_trace_stage"] = e
         summary["commands"]["configs[4]"] = "RTGPU_RENDER_LANES=1 rocprofv3 [...] -- python3 scripts/prof_c5.py (two frames; figures per frame)"
+    # ---- configs[2] / configs[3]: trace_stage_kernel over frames of the interior scene (two 1080p frames / one 4K frame)
+    for key, name, frames in (("interior_1080p_trace_stage", "i1080", 2.0), ("interior_4k_trace_stage", "i4k", 1.0)):
+        sti = glob.glob(os.path.join(src, "trace_" + name, "*", "*_kernel_stats.csv"))
+        if not sti:
+            continue
+        shutil.copy(sti[0], os.path.join(dst, tag + "_" + name + "_kernel_stats.csv"))
+        kti = kernel_time(sti[0], "trace_stage_kernel")
+        ci = {k: sum(v) / frames for k, v in counters(sorted(glob.glob(os.path.join(src, "pmc_" + name + "_*"))), "trace_stage_kernel").items()}
+        e = {"kernel": "trace_stage_kernel<kTraceSingle>", "kernel_trace": kti}
+        if kti:
+            e["trace_stage_ms_per_frame"] = kti["total_ns"] / frames / 1e6
+            e.update(derived(ci, kti["total_ns"] / frames / 1e9))
+            if "hbm_bytes" in e:
+                e["hbm_bytes_per_frame"] = e.pop("hbm_bytes")
+        summary[key] = e
+    summary["commands"]["configs[2] / configs[3]"] = "RTGPU_RENDER_LANES=1 rocprofv3 [...] -- python3 scripts/prof_interior.py 1080p | 4k (two frames / one frame; figures per frame)"
     json.dump(summary, open(os.path.join(dst, tag + "_pmc_summary.json"), "w"), indent=1)
     print(json.dumps(summary, indent=1))
 

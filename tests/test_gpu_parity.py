@@ -271,16 +271,55 @@ def test_render_with_thin_lens_matches_oracle():
     cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
     cam.aperture, cam.focal_distance = 0.06, 2.4
     st = abi.make_settings(W, H, geometry_aa=8, material_aa=4, seed=4)
-    ref, rstats = oracle.OracleScene(sc).render(cam, st)
+    S = oracle.OracleScene(sc)
+    ref, rstats = S.render(cam, st)
     with api.Scene(sc) as g:
         img, stats = api.Renderer().render(g, cam, st)
     assert np.isfinite(img).all()
-    assert rel_rmse(img, ref) <= 2e-3   # lens points differ in the last bits, which can flip single hit decisions
+    assert rel_rmse(img, ref) <= 1e-4   # measured 1.2e-5: one pixel differs, by a last-bit difference in one acos
+    check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=4, max_unattributed=1)
     assert stats.primary_rays == rstats.primary_rays
 
 
 def rel_rmse(a, b):
     return float(np.sqrt(np.mean((a - b) ** 2)) / max(float(np.mean(b)), 1e-12))
+
+
+def differing_pixels(img, ref, tol=1e-4):
+    """Pixels in which some channel is off by more than `tol` of the pixel's brightest channel (or of the image mean for
+    dark pixels)."""
+    scale = np.maximum(ref.max(axis=2), float(ref.mean()))
+    return np.abs(img - ref).max(axis=2) > tol * scale
+
+
+def check_image_and_attribute_differences(S, cam, st, img, ref, max_differing, max_unattributed, photon_gather=False):
+    """The image bar with its exceptions accounted for.  Outside the differing pixels the images agree to 1e-4 relative RMSE.
+    The differing pixels are few (`max_differing`), and each is shown to be a documented case by making the oracle differ in
+    that one respect and getting the GPU's pixel out of it:
+      * a last-bit difference between glibc and the device's math library in ONE call of acos / atan2 / tan / sin / cos /
+        pow flips a decision further down the path (oracle.attribute_pixel_to_libm: the call's result moved by one or two
+        units in the last place);
+      * photon renders: photons tie for the 20th place once their distances are rounded (the reference compares rounded
+        square roots, the kernels squared distances; oracle.set_gather_rule).
+    At most `max_unattributed` pixels may stay unexplained by a single such change (two at once are not searched for).
+    Returns (number of differing pixels, number attributed)."""
+    D = differing_pixels(img, ref)
+    assert rel_rmse(img[~D], ref[~D]) <= 1e-4
+    assert int(D.sum()) <= max_differing, "%d pixels differ" % int(D.sum())
+    floor = float(ref.mean())
+    attributed = 0
+    for y, x in zip(*np.nonzero(D)):
+        if S.attribute_pixel_to_libm(cam, st, x, y, img[y, x], 1e-4, floor) is not None:
+            attributed += 1
+            continue
+        if photon_gather:
+            S.set_gather_rule(1)
+            p = S.render_pixel_probe(cam, st, x, y)[0]
+            S.set_gather_rule(0)
+            if np.abs(p - img[y, x]).max() <= 1e-4 * max(float(img[y, x].max()), floor):
+                attributed += 1
+    assert int(D.sum()) - attributed <= max_unattributed, "%d of %d differing pixels unexplained" % (int(D.sum()) - attributed, int(D.sum()))
+    return int(D.sum()), attributed
 
 
 @pytest.mark.parametrize("name,G,M,W,H", [("box", 4, 4, 48, 36), ("box", 16, 16, 32, 24), ("mirror", 4, 16, 40, 30), ("c1", 4, 8, 80, 60), ("c1-meshes", 4, 8, 80, 60),
@@ -356,7 +395,8 @@ def test_render_interior_glossy_floor_matches_oracle():
     W, H = 160, 90
     cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
     st = abi.make_settings(W, H, geometry_aa=4, material_aa=4, max_path_length=9, seed=1)
-    ref, _ = oracle.OracleScene(sc).render(cam, st)
+    S = oracle.OracleScene(sc)
+    ref, _ = S.render(cam, st)
     with api.Scene(sc) as g:
         img, _ = api.Renderer().render(g, cam, st)
         nan_o = np.array([[1.0, 1.0, 1.0], [np.nan, 1.0, 1.0]], np.float32)
@@ -364,7 +404,15 @@ def test_render_interior_glossy_floor_matches_oracle():
         assert list(g.trace_rays(nan_o, nan_d)["inst"]) == [abi.INVALID_ID] * 2
         assert list(g.test_visibility(nan_o, nan_d, 100.0)) == [0, 0]
     assert np.isfinite(img).all()
-    assert rel_rmse(img, ref) <= 2e-3  # a few exact-distance ties on the axis-aligned walls pick the other triangle's normal
+    # Measured: 13 of 14 400 pixels differ (relative RMSE 2.3e-4 with them, 5e-6 without); 12 of them are reproduced by the
+    # oracle when ONE of the pixel's libm calls (atan2, acos or pow, in the glossy floor's sampling) is moved by one unit in the
+    # last place.  Exact-distance ties, which an earlier version of this test blamed, are not the cause: with the kernels'
+    # tie rule (oracle.set_closest_rule(1)) the oracle renders the very same pixels as without.
+    n_diff, n_attr = check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=20, max_unattributed=2)
+    S.set_closest_rule(1)
+    for y, x in list(zip(*np.nonzero(differing_pixels(img, ref))))[:4]:
+        assert np.array_equal(S.render_pixel_probe(cam, st, x, y)[0], ref[y, x])
+    S.set_closest_rule(0)
 
 
 def test_render_statistically_matches_other_seeds():

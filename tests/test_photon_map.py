@@ -6,6 +6,7 @@ import numpy as np
 import pytest
 
 import oracle
+from test_gpu_parity import check_image_and_attribute_differences
 from raytracer_amd import abi, api, scenes
 from raytracer_amd.abi import MAT_DIFFUSE, InstanceData, MaterialData, MeshData, SceneData
 
@@ -184,7 +185,8 @@ def test_gpu_gather_by_whole_waves_matches_the_oracle(budget, monkeypatch):
         st = abi.make_settings(48, 36, geometry_aa=2, material_aa=4, seed=11)
         ref, _ = S.render(cam, st)
         img, _ = api.Renderer().render(g, cam, st)
-    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-3
+    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-4
+    check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=8, max_unattributed=3, photon_gather=True)
 
 
 @pytest.mark.gpu
@@ -205,7 +207,8 @@ def test_gpu_render_with_photon_map_matches_the_oracle(depth):
         g.set_photons(ph[:0], abi.PM_NONE, 0)
         plain, _ = api.Renderer().render(g, cam, st)
     assert np.isfinite(img).all()
-    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-3
+    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-4      # measured 1.2e-5 / 2.1e-5: two or three pixels differ
+    check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=8, max_unattributed=3, photon_gather=True)
     assert stats.extension_rays <= rstats.extension_rays * 1.0001 and stats.extension_rays >= 0.97 * rstats.extension_rays
     # removing the map gives the path-traced image again (same order of brightness: the reference's two estimators
     # differ by the 20 / 19 of the density estimate, the last emission task traced twice and the path tracer's own
@@ -237,8 +240,16 @@ def test_gpu_render_in_caustics_mode_matches_the_oracle(scene_name):
         g.set_photons(ph[:0], abi.PM_NONE, 0)
         plain, _ = api.Renderer().render(g, cam, st)
     assert np.isfinite(img).all() and not np.allclose(img, plain)
-    assert np.isclose(img, ref, rtol=2e-3, atol=1e-5).all(axis=2).mean() > 0.99
-    assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 2e-3
+    if scene_name == "mirror":
+        assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 1e-4     # measured 8e-7, no pixel differs
+        check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=4, max_unattributed=1, photon_gather=True)
+    else:
+        # Measured: 15 of 3 072 pixels differ (relative RMSE 8.6e-4 with them, 2e-6 without).  Eight are reproduced by one
+        # change to the oracle: seven by the exact photon search (photons that tie for the 20th place once their distances
+        # are rounded to a float square root), one by a last-bit move of one pow; the others need more than one such change
+        # at once (a path through the glass ball meets several gathers and refractions), which is not searched for.
+        assert np.sqrt(np.mean((img - ref) ** 2)) / ref.mean() <= 2e-3
+        check_image_and_attribute_differences(S, cam, st, img, ref, max_differing=25, max_unattributed=11, photon_gather=True)
 
 
 @pytest.mark.gpu
