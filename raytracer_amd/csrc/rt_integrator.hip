@@ -372,17 +372,13 @@ template <bool FIRST, bool RICH>
 // five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took 98-111 of its own
 // accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and lose, and so does
 // five for the RICH variants)
-__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(ShadeArgs byValue)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(ShadeArgs)
 {
-#ifdef RT_SHADE_ARGS_BY_VALUE
-    const ShadeArgs& A = byValue;
-#else
     // The arguments are read where they are used, through the kernel-argument segment's address, instead of through the
     // parameter: as a parameter every field the kernel uses is loaded into scalar registers at its entry and stays there,
     // far more than a wave has, and the compiler then keeps them in lanes of a vector register and fetches them back
     // one v_readlane at a time (a fifth of the kernel's vector instructions).
     const ShadeArgs& A = *(const ShadeArgs*)__builtin_amdgcn_kernarg_segment_ptr();
-#endif
     const SceneView& sv = A.sv;
     const Pool& pool = A.pool;
     const rtgpu_render_settings& st = A.st;

@@ -75,25 +75,6 @@ def scatter_to_frame(buffers: List[np.ndarray], settings, tile_size: int, frame:
     return frame
 
 
-# ---- row bands: the rectangles separate reference processes would render into TILE files ---------
-
-def band_height(height: int, world: int, bands_per_rank: int = 4) -> int:
-    """Rows per band: about bands_per_rank interleaved bands for every rank, at least 1 row."""
-    return max(1, -(-height // (world * bands_per_rank)))
-
-
-def rank_bands(height: int, world: int, rank: int, bands_per_rank: int = 4) -> List[Tuple[int, int]]:
-    """Half-open row ranges [y0, y1) of `rank`: band b goes to rank b % world."""
-    bh = band_height(height, world, bands_per_rank)
-    out = []
-    b = 0
-    for y0 in range(0, height, bh):
-        if b % world == rank:
-            out.append((y0, min(height, y0 + bh)))
-        b += 1
-    return out
-
-
 # ---- the gather ------------------------------------------------------------------------------------
 
 def gather_compact(local, settings, tile_size: int, rank: int, world: int, group=None):

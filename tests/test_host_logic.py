@@ -28,17 +28,6 @@ def test_scene_generators():
     assert small.n_triangles() > 1000
 
 
-def test_band_partition_covers_every_row_once():
-    for H in (1, 7, 48, 1080, 2160):
-        for world in (1, 2, 4, 8):
-            seen = np.zeros(H, dtype=int)
-            for r in range(world):
-                for y0, y1 in distributed.rank_bands(H, world, r):
-                    assert 0 <= y0 < y1 <= H
-                    seen[y0:y1] += 1
-            assert np.all(seen == 1)
-
-
 def _pattern(W, H):
     ys = np.arange(H, dtype=np.float32)[:, None, None]
     xs = np.arange(W, dtype=np.float32)[None, :, None]
