@@ -465,8 +465,8 @@ def cpu_baseline(res, abi, api, torch, dev):
     _, stats = osc.render(res["cam"], st, threads=threads)
     dt = time.perf_counter() - t0
     rate = (stats.primary_rays + stats.extension_rays + stats.shadow_rays) / dt
-    # second tile sized for about 12 s at that rate
-    scale = max(1.0, min(12.0, (12.0 / max(dt, 1e-3)) ** 0.5))
+    # second tile sized for about 15 s at that rate
+    scale = max(1.0, min(28.0, (15.0 / max(dt, 1e-3)) ** 0.5))
     tw, th = int(48 * scale) // 2 * 2, int(27 * scale) // 2 * 2
     st = tile_settings(tw, th)
     t0 = time.perf_counter()

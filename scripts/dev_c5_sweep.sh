@@ -1,8 +1,7 @@
 #!/bin/bash
-# configs[4] frame against mesh-tree build parameters and stealing thresholds
-for leaf in 4 8 12; do for tc in 1 2; do
-  RTGPU_BUILD_MAX_LEAF=$leaf RTGPU_BUILD_TRAVERSAL_COST=$tc timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
-done; done
-for idle in 1 8 32; do
-  RTGPU_STEAL_MIN_IDLE=$idle timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
-done
+# configs[4] frame against batch size / batches in flight
+timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
+RTGPU_BATCH_PATHS=8388608 RTGPU_RENDER_LANES=4 timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
+RTGPU_BATCH_PATHS=4194304 RTGPU_RENDER_LANES=8 timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
+RTGPU_BATCH_PATHS=4194304 RTGPU_RENDER_LANES=4 timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1
+RTGPU_BATCH_PATHS=2097152 RTGPU_RENDER_LANES=8 timeout -k 10 200 python scripts/dev_c5_frame.py 2>&1 | tail -1 || exit 1

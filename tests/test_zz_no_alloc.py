@@ -35,3 +35,30 @@ def test_static_workspace_render_matches_the_allocating_one_twice_in_a_row():
         st = abi.make_settings(64, 48, geometry_aa=1024, material_aa=1024)
         with pytest.raises(api.RtgpuError, match="static workspace"):
             r.render_device_static(g, cam, st, got, stream)
+
+
+def test_static_workspace_render_under_stream_capture():
+    """What the entry point is for: the whole call is captured into a HIP graph (nothing in it allocates, waits or reads
+    back), and replaying the graph renders the frame again, bit for bit."""
+    import torch
+    sc, cam_m, yfov = scenes.box_scene(with_mirror=True)
+    dev = torch.device("cuda", 0)
+    W, H = 96, 64
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=2, material_aa=4, seed=21)
+    r = api.Renderer()
+    with api.Scene(sc) as g:
+        want = torch.zeros((H, W, 3), dtype=torch.float32, device=dev)
+        r.render_device(g, cam, st, want, torch.cuda.current_stream())
+        got = torch.full((H, W, 3), -1.0, dtype=torch.float32, device=dev)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream(device=dev)
+        with torch.cuda.graph(graph, stream=side):
+            r.render_device_static(g, cam, st, got, torch.cuda.current_stream())
+        torch.cuda.synchronize()
+        for _ in range(2):
+            got.fill_(-1.0)
+            graph.replay()
+            torch.cuda.synchronize()
+            assert torch.equal(got, want)
