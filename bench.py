@@ -467,7 +467,7 @@ def cpu_baseline(res, abi, api, torch, dev):
     rate = (stats.primary_rays + stats.extension_rays + stats.shadow_rays) / dt
     # second tile sized for about 15 s at that rate
     scale = max(1.0, min(28.0, (15.0 / max(dt, 1e-3)) ** 0.5))
-    tw, th = int(48 * scale) // 2 * 2, int(27 * scale) // 2 * 2
+    tw, th = min(W, int(48 * scale) // 2 * 2), min(H, int(27 * scale) // 2 * 2)
     st = tile_settings(tw, th)
     t0 = time.perf_counter()
     ref, stats = osc.render(res["cam"], st, threads=threads)
@@ -496,6 +496,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the other configurations reported beside the headline value")
     ap.add_argument("--no-c5", action="store_true", help="skip the 49.8 M-triangle configuration (about 40 s of scene set-up)")
+    ap.add_argument("--no-c3", action="store_true", help="skip the 3840x2160 256-spp interior frame (about 5 s of rendering)")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--profile-tag", default="r03", help="profiles/<tag>_pmc_summary.json holds the committed counters quoted beside the live numbers")
     args = ap.parse_args()
@@ -570,7 +571,7 @@ def main():
                  ("configs[2]", lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 1920, 1080, 8, 8, dev,
                                                     "configs[2]: interior scene, %d triangles, 1920x1080, 8x8 spp, path length 9",
                                                     "trace_stage_kernel<kTraceSingle>")),
-                 ("configs[3]", lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 3840, 2160, 16, 16, dev,
+                 ("configs[3]", None if args.no_c3 else lambda: bench_frame(torch, api, abi, *scenes.interior_scene(scenes.C3_DETAIL), 3840, 2160, 16, 16, dev,
                                                     "configs[3] on one GPU: interior scene, %d triangles, 3840x2160, 16x16 = 256 spp, path length 9 (the "
                                                     "single-GPU reference of the 2 / 4 / 8-GPU runs)", "trace_stage_kernel<kTraceSingle>", frames=1))]
         if not args.no_c5:
@@ -578,6 +579,8 @@ def main():
                                                             "configs[4]: 38 copies of the blob flattened into one mesh, %d triangles, camera inside the cluster, "
                                                             "diffuse, 1920x1080, 4x4 = 16 spp, path length 9", "trace_stage_kernel<kTraceSingle>", frames=2)))
         for name, fn in steps:
+            if fn is None:
+                continue
             try:
                 extras[name] = fn()
             except Exception as e:  # noqa: BLE001  (the headline line must still be printed)

@@ -1679,13 +1679,20 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
     const uint64_t pathsPerPixel = (uint64_t)G * M;
 
-    uint64_t capPaths = 1ull << 24; // paths resident per batch (about 110 bytes of state each); 2^23 measured 1.6 % slower on the 4K frame, 2^25 no faster
+    // paths resident per batch (about 110 bytes of state each): as many as a queue entry's 25 bits of path allow (on the 4K
+    // frame 2^24 measured 1.5 % slower, 2^23 3 %), but a call is cut into at least two batches, so that two are in flight
+    int lanes = 2;
+    if (const char* e = std::getenv("RTGPU_RENDER_LANES")) lanes = std::max(1, std::min(8, std::atoi(e)));
+    uint64_t capPaths = 1ull << kQueuePathBits;
+    bool capGiven = false;
     if (const char* e = std::getenv("RTGPU_BATCH_PATHS")) {
         const long long v = std::atoll(e);
-        if (v > 0) capPaths = std::min<uint64_t>((uint64_t)v, 1ull << kQueuePathBits);   // a queue entry holds 25 bits of path
+        if (v > 0) { capPaths = std::min<uint64_t>((uint64_t)v, 1ull << kQueuePathBits); capGiven = true; }
     }
     uint64_t pixelsPerBatch = std::max<uint64_t>(1, capPaths / pathsPerPixel);
     pixelsPerBatch = std::min<uint64_t>(pixelsPerBatch, nPixelsTotal);
+    if (!capGiven && !profile && nPixelsTotal * pathsPerPixel >= (1ull << 22) && (nPixelsTotal + pixelsPerBatch - 1) / pixelsPerBatch < (uint64_t)lanes)
+        pixelsPerBatch = (nPixelsTotal + (uint64_t)lanes - 1) / (uint64_t)lanes;
     const uint64_t P = pixelsPerBatch * pathsPerPixel;
     const uint64_t S = pixelsPerBatch * G;
     // a batch holds whole pixels and a queue entry 25 bits of path: more paths per pixel than that would alias with the vertex bits
@@ -1695,8 +1702,6 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
     // with its own workspace and host thread: the thin late-bounce launches of one batch overlap with the other
     // batch's kernels.
     const uint64_t nBatches = (nPixelsTotal + pixelsPerBatch - 1) / pixelsPerBatch;
-    int lanes = 2;
-    if (const char* e = std::getenv("RTGPU_RENDER_LANES")) lanes = std::max(1, std::min(8, std::atoi(e)));
     lanes = (int)std::min<uint64_t>((uint64_t)lanes, nBatches);
     if (profile) lanes = 1;   // one batch at a time: the launches of two streams would overlap and stretch each other's spans
     StageTimer timer;

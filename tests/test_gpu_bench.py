@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
         "dtype", "data", "config"}
-SMALL = ["--width", "960", "--height", "540", "--gaa", "4", "--maa", "4", "--subdiv", "6"]
+SMALL = ["--width", "960", "--height", "540", "--gaa", "4", "--maa", "4", "--subdiv", "6", "--no-c3"]
 
 
 def check_line(out, n_gpus, steps):
@@ -27,8 +27,16 @@ def check_line(out, n_gpus, steps):
 
 
 def check_roofline(r):
-    assert r["bound"] in ("l2", "hbm") and r["peak"] in (34500.0, 8000.0) and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
-    assert 0 < r["frac"] < 1
+    """bound = the resource that binds (VALU issue, from committed counters of the same kernel and workload) with frac < 1, or --
+    without such counters -- the algorithmic bytes against the HBM peak, which a cache-resident scene may exceed; the
+    algorithmic rate against the L2 peak stays below 1 either way."""
+    assert r["bound"] in ("valu_issue", "hbm") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert {"achieved", "peak", "unit", "traffic", "algorithmic_GBps", "frac_of_l2_peak", "frac_of_hbm_peak"} <= set(r)
+    assert 0 < r["frac_of_l2_peak"] < 1
+    if r["bound"] == "valu_issue":
+        assert 0 < r["frac"] < 1 and r["peak"] == 614.4 and "committed profile" in r["counters"]["source"] and r["traffic"] > 0
+    else:
+        assert r["peak"] == 8000.0 and r["frac"] > 0 and "counters" not in r
 
 
 def test_bench_single_gpu_line():
@@ -42,8 +50,8 @@ def test_bench_single_gpu_line():
     ex = d["extras"]
     check_roofline(ex["configs[1]"]["primary"]["roofline"])
     assert "counters" not in d["roofline"]   # a reduced frame does not quote the committed counters of the full one
-    b = ex["configs[1]"]["bounce"]["roofline"].get("binding")   # configs[1] is run at its full size: the committed counters apply
-    assert b is None or (b["resource"] == "valu_issue" and 0 < b["frac"] < 1 and "committed profile" in b["source"])
+    assert ex["configs[0]"]["identical_to_oracle"] is True and ex["configs[0]"]["cpu_baseline"]["value"] > 0
+    check_roofline(ex["configs[0]"]["roofline"])
     check_roofline(ex["configs[1]"]["bounce"]["roofline"])
     check_roofline(ex["configs[2]"]["roofline"])
     assert ex["configs[2]"]["ms_per_frame"] > 0 and ex["configs[2]"]["rays_per_frame"] > 1e8
