@@ -357,12 +357,16 @@ int rtgpu_render_profile_device(const rtgpu_scene* scene, const rtgpu_camera* ca
                                 float* d_rgb_out, rtgpu_render_profile* profile, void* hip_stream);
 
 /* rtgpu_render_device without any allocation.  No counterpart in the reference: it is for callers that cannot allocate
- * device memory while they run -- code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.
+ * device memory while they run -- tight serving loops, harnesses that forbid hipMalloc, code between the begin and end of a
+ * stream capture (every call it makes can be captured; replaying such a graph has not been made to work on ROCm 7.2 and is
+ * not supported).
  * The integrator's workspace is a fixed array of RTGPU_STATIC_WORKSPACE_BYTES inside the library (each GPU the library
- * runs on holds it until the process ends), paths are rendered in batches that fit it, all work is enqueued on hip_stream
- * and the call returns without waiting (the caller synchronises; no ray statistics).  Calls that overlap on one GPU share
- * the array and race: one call at a time per GPU.  RTGPU_ERR_LIMIT when one pixel's geometry_aa * material_aa paths
- * (about 140 bytes each) do not fit the array; n_gpus must be 0 or 1.  The image is bit-identical to rtgpu_render_device's. */
+ * runs on holds it until the process ends; its address is looked up when a scene is made on the device), paths are rendered
+ * in batches that fit it, all work is enqueued on hip_stream and the call returns without waiting (the caller synchronises;
+ * no ray statistics).  Nothing is read back, so every batch enqueues all 2 * max_path_length + 2 passes over its full path
+ * count.  Calls that overlap on one GPU share the array and race: one call at a time per GPU.  RTGPU_ERR_LIMIT when one
+ * pixel's geometry_aa * material_aa paths (about 140 bytes each) do not fit the array; n_gpus must be 0 or 1.  The image is
+ * bit-identical to rtgpu_render_device's. */
 #define RTGPU_STATIC_WORKSPACE_BYTES (64u << 20)
 int rtgpu_render_device_static(const rtgpu_scene* scene, const rtgpu_camera* camera, const rtgpu_render_settings* settings,
                                float* d_rgb_out, void* hip_stream);

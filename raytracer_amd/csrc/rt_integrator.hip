@@ -1805,8 +1805,8 @@ hipError_t render_wavefront(const rtgpu_scene& scene, const rtgpu_camera& cam, c
 }
 
 // ---- the render that allocates nothing -----------------------------------------------------------------
-// For callers that cannot allocate device memory while they run (code under HIP graph capture, serving loops, harnesses
-// that forbid hipMalloc): the integrator's workspace is a fixed array inside the library's code object instead of a
+// For callers that cannot allocate device memory while they run (serving loops, harnesses that forbid hipMalloc, code
+// inside a stream capture): the integrator's workspace is a fixed array inside the library's code object instead of a
 // hipMalloc'ed block, batches are sized to fit it, everything is enqueued on the caller's stream, and nothing is read back
 // (every pass is launched over the batch's full path count and finds its queue length on the device).
 namespace {
