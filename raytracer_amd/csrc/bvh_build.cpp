@@ -390,11 +390,15 @@ std::vector<Node128> collapse_tree4(const std::vector<Node64>& binary, uint32_t&
 namespace {
 
 // One node.  Per axis: origin = the smallest low plane of the node's children, step = a little more than 1/255 of the
-// extent, low planes rounded down and high planes rounded up on that grid.  The kernels decode a plane as
-// fma(q, step, origin - ray origin): against the exact (plane - ray origin) that differs by the rounding of
-// (origin - ray origin) instead of (plane - ray origin), at most 2^-24 of the node's extent more, so every plane off
-// the grid's ends is moved out by 2^-22 of the extent before it is rounded (the grid's ends decode exactly).  An axis on
-// which some child box is not finite gets a grid that spans all finite numbers: the child is entered whatever the ray.
+// extent, low planes rounded down and high planes rounded up on that grid.  The kernels decode a plane's distance along a
+// ray as fma(q, step / d, (origin - ray origin) / d).  Against the exact (plane - ray origin) / d that is off by two kinds
+// of rounding: one proportional to the node's extent (q * step, at most 2^-23 of the extent) -- every plane off the grid's
+// first point is moved out by 2^-22 of the extent before it is rounded, which covers it (the first point decodes without
+// it: q = 0 adds nothing) -- and one proportional to the distance between the ray's origin and the node (about 3 * 2^-24 of
+// it: the subtraction, the product with 1 / d and the fma).  The second kind is not the builder's to cover: the kernels
+// rely on the 1e-4 padding of triangle boxes for rays that start near the tree and widen the decoded distances themselves
+// for the others (plane_offsets, rt_trace_inl.h).  An axis on which some child box is not finite gets a grid that spans all
+// finite numbers: the child is entered whatever the ray.
 NodeQ64 quantize_node(const Node128& n)
 {
     NodeQ64 q{};
