@@ -373,7 +373,7 @@ def bench_c2(args, torch, api, abi, scenes, dev):
     out["primary"] = {"workload": "configs[1]: %d triangles, %dx%d primary rays, closest hit" % (sc.n_triangles(), W, H),
                       "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
                       "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
-    if counters and "c2_primary" in counters:
+    if counters and "c2_primary" in counters and args.subdiv == 8:   # (the blob the profile was taken on)
         attach_counters(out["primary"]["roofline"], counters["c2_primary"], src, "launch")
     # bounce rays: from every primary hit point, a direction in the hemisphere of the (radial) outward normal
     h = hits.cpu().numpy().view(np.uint32)
@@ -395,7 +395,7 @@ def bench_c2(args, torch, api, abi, scenes, dev):
     out["bounce"] = {"workload": "configs[1] scene, %d diffuse-bounce rays from the primary hit points in pixel order (incoherent)" % n,
                      "mrays_per_s": n / ms / 1e3, "ms_per_launch": ms,
                      "roofline": roofline(ray_bytes(n, boxes, tris, 16.0), ms, int(info.device_bytes), "trace_closest_steal_kernel<false>", extra)}
-    if counters and "c2_bounce" in counters:
+    if counters and "c2_bounce" in counters and args.subdiv == 8:
         attach_counters(out["bounce"]["roofline"], counters["c2_bounce"], src, "launch")
     # the host-pointer entry point (rays and hits cross PCIe inside the call); the median of 9 calls: copies of a call that
     # follows the release of large device buffers wait for the driver's own DMA work for some tens of milliseconds

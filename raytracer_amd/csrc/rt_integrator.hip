@@ -76,7 +76,21 @@ constexpr uint32_t kQueuePathMask = (1u << kQueuePathBits) - 1u;
 static_assert((1u << kQueuePathBits) == (uint32_t)RTGPU_MAX_PATHS_PER_PIXEL, "the path limit the header states is the queue entry's");
 static_assert(kQueuePathBits + 7 <= 32 && 64 + 1 <= (1 << 7), "a queue entry holds the path and the next vertex (at most max_path_length = 64)");
 
-constexpr uint32_t kPoolCounters = 8;   // words of Pool::counters
+// The extension and the shadow queue are cut into kQueueSegs segments, each with a length of its own: workgroup b of a
+// shade pass appends to segment b % kQueueSegs, and the workgroups that read a queue take segment b % kQueueSegs, block
+// b / kQueueSegs of it.  Atomics on one address are served one after the other (6-11 ns each on this chip), and a pass
+// makes one per workgroup and queue: with a single length per queue that chain was as long as the pass itself.  A
+// segment holds what the workgroups of one residue can append, segCap = 256 * ceil(workgroups / kQueueSegs) entries at
+// most; a path leaves at most one extension entry behind, so a segment never grows from pass to pass.
+#ifndef RT_QUEUE_SEGMENTS
+#define RT_QUEUE_SEGMENTS 8
+#endif
+constexpr uint32_t kQueueSegs = RT_QUEUE_SEGMENTS;
+constexpr uint32_t kCtrLine = 32;   // words (128 bytes) between two lengths that are added to at the same time
+// one pass's counters: words 2 / 3 / 4 = photon queue length, prefix rays repeated per material sample, photon tail queue
+// length; word kCtrExt + s * kCtrLine = length of extension segment s, kCtrShadow + s * kCtrLine of shadow segment s
+constexpr uint32_t kCtrExt = kCtrLine, kCtrShadow = kCtrLine * (1 + kQueueSegs);
+constexpr uint32_t kCtrStride = kCtrLine * (1 + 2 * kQueueSegs);
 
 #ifdef RT_SHADE_STATS
 // developer build: lanes and waves that reach marked places of the later shade passes (slot 2k = lanes, 2k + 1 = waves)
@@ -154,7 +168,8 @@ struct Pool {
     float4* cDir;
     float4* cThrColor;
     float4* cBase;
-    uint32_t* counters;   // [0] extension queue size, [1] shadow queue size, [2] photon queue size, [3] prefix rays repeated per material sample, [4] photon tail queue size
+    uint32_t* counters;   // [pass][kCtrStride]
+    uint32_t segCap;      // entries between the starts of two segments of qA / qB / qShadow
 };
 
 __device__ __forceinline__ float4 f4(float x, float y, float z, float w)
@@ -390,11 +405,13 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     uint32_t* __restrict__ cnt = A.cnt;
     // FIRST: every path of the batch; later passes: the extension queue the previous pass filled, whose length is read
     // here (the grid is sized from an upper bound the host knows, surplus workgroups find nothing to do)
-    const uint32_t nIn = FIRST ? nPaths : cntIn[0];
-    if (blockIdx.x * (uint32_t)kShadeBlock >= nIn) return;   // a surplus workgroup (the grid covers an upper bound of the queue): nothing to regroup or push
+    const uint32_t seg = blockIdx.x % kQueueSegs;   // the segment this workgroup appends to and (later passes) reads
+    const uint32_t inBlock = FIRST ? blockIdx.x : blockIdx.x / kQueueSegs;
+    const uint32_t nIn = FIRST ? nPaths : cntIn[kCtrExt + seg * kCtrLine];
+    if (inBlock * (uint32_t)kShadeBlock >= nIn) return;   // a surplus workgroup (the grid covers an upper bound of the queue): nothing to regroup or push
     SHADE_T0(0);
     SHADE_T0(1);
-    const uint32_t q = blockIdx.x * (uint32_t)kShadeBlock + threadIdx.x;
+    const uint32_t q = inBlock * (uint32_t)kShadeBlock + threadIdx.x;
     bool pushExt = false, pushShadow = false, pushPhoton = false, repeated = false;
     uint32_t nextVertex = 0;   // the vertex the next pass samples for a path that goes on: the one after a vertex that waits for its own ray
     const uint32_t G = (uint32_t)st.geometry_aa, M = (uint32_t)st.material_aa;
@@ -404,7 +421,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     if (FIRST && it.active) it.active = pool.sLive[q / M] != 0;
     uint32_t vertexGuess = 0;
     if (it.active) {
-        const uint32_t entry = FIRST ? q : qIn[q];
+        const uint32_t entry = FIRST ? q : qIn[seg * pool.segCap + q];
         it.p = entry & kQueuePathMask;
         const uint32_t s0 = it.p / M;
         it.j = it.p % M;
@@ -1022,7 +1039,8 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
         if ((m >> pieceC) & 1u) pool.rayA.base[(size_t)ps * 4 + pieceC] = tile[src][(pieceC + src) & 3];
     }
     SHADE_T0(7);
-    queue_push2<kShadeBlock>(qExt, cnt + 0, pushExt, pool.qShadow, cnt + 1, pushShadow, p, p | (nextVertex << kQueuePathBits));
+    queue_push2<kShadeBlock>(qExt + seg * pool.segCap, cnt + kCtrExt + seg * kCtrLine, pushExt, pool.qShadow + seg * pool.segCap, cnt + kCtrShadow + seg * kCtrLine,
+                             pushShadow, p, p | (nextVertex << kQueuePathBits));
     if (RICH) {
         if (sv.pmMode != RTGPU_PM_NONE) queue_push1<kShadeBlock>(pool.qPhoton, cnt + 2, pushPhoton, p);   // uniform branch
     }
@@ -1039,12 +1057,12 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
 // Both run after a shade pass and are independent of each other, so one launch carries both: the
 // first workgroups trace the extension rays (closest hit), the rest the shadow rays (any hit).
 template <int MODE>
-__device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& pool, uint32_t block, uint32_t n,
+__device__ __forceinline__ void shadow_block(const SceneView& sv, const Pool& pool, const uint32_t* __restrict__ queue, uint32_t block, uint32_t n,
                                              typename TraceLds<MODE>::type& lds, int lane)
 {
     const uint32_t q = block * 64u + lane;
     const bool has = q < n;
-    const uint32_t p = pool.qShadow[has ? q : 0u];
+    const uint32_t p = queue[has ? q : 0u];
     float4 ra = pool.rayA[p], rb = pool.rayB[p];
     // a glass vertex asks whether the light along the direction it did not take is visible
     const bool sticky = sv.hasGlass && (__float_as_uint(rb.w) & ST_GLASS_STICKY) != 0;
@@ -1077,11 +1095,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == kTra
 {
     __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
-    // queue lengths as the shade pass left them; the grid covers an upper bound of both
-    const uint32_t nExt = cnt[0], nShadow = cnt[1];
+    // workgroup b: block b / kQueueSegs of segment b % kQueueSegs, the segment's extension entries first.  Lengths as
+    // the shade pass left them; the grid covers an upper bound of the longest segment's two queues together
+    const uint32_t seg = blockIdx.x % kQueueSegs, block = blockIdx.x / kQueueSegs;
+    const uint32_t nExt = cnt[kCtrExt + seg * kCtrLine], nShadow = cnt[kCtrShadow + seg * kCtrLine];
     const uint32_t extBlocks = (nExt + 63u) / 64u, shadowBlocks = (nShadow + 63u) / 64u;
-    if (blockIdx.x < extBlocks) extend_block<MODE>(sv, pool, extQueue, blockIdx.x, nExt, lds, lane);
-    else if (blockIdx.x - extBlocks < shadowBlocks) shadow_block<MODE>(sv, pool, blockIdx.x - extBlocks, nShadow, lds, lane);
+    if (block < extBlocks) extend_block<MODE>(sv, pool, extQueue + seg * pool.segCap, block, nExt, lds, lane);
+    else if (block - extBlocks < shadowBlocks) shadow_block<MODE>(sv, pool, pool.qShadow + seg * pool.segCap, block - extBlocks, nShadow, lds, lane);
 }
 
 // The same stage with every ray traversed on its own by one lane (nearer child first, pruned by its own hits) and the
@@ -1104,14 +1124,15 @@ __global__ __launch_bounds__(64) void trace_stage_count_kernel(SceneView sv, Poo
 {
     __shared__ int stack[kLdsStack][64];
     const int lane = threadIdx.x;
-    const uint32_t nExt = cnt[0], nShadow = cnt[1];
+    const uint32_t seg = blockIdx.x % kQueueSegs, block = blockIdx.x / kQueueSegs;
+    const uint32_t nExt = cnt[kCtrExt + seg * kCtrLine], nShadow = cnt[kCtrShadow + seg * kCtrLine];
     const uint32_t extBlocks = (nExt + 63u) / 64u, shadowBlocks = (nShadow + 63u) / 64u;
     uint32_t nb = 0, nt = 0;
-    if (blockIdx.x < extBlocks) {
-        const uint32_t q = blockIdx.x * 64u + lane;
+    if (block < extBlocks) {
+        const uint32_t q = block * 64u + lane;
         const bool has = q < nExt;
         if (has) {
-            const uint32_t p = extQueue[q] & kQueuePathMask;
+            const uint32_t p = extQueue[seg * pool.segCap + q] & kQueuePathMask;
             const float4 ra = pool.rayA[p], rb = pool.rayB[p];
             const TraceResult r = solo_closest(sv, f3(ra.x, ra.y, ra.z), f3(rb.x, rb.y, rb.z), stack, lane, nb, nt);
             pool.hit[p] = f4(r.t, __uint_as_float(r.slot), r.beta, r.gamma);
@@ -1120,11 +1141,11 @@ __global__ __launch_bounds__(64) void trace_stage_count_kernel(SceneView sv, Poo
         wave_add64(work + 0, has ? 1u : 0u, lane);
         wave_add64(work + 1, nb, lane);
         wave_add64(work + 2, nt, lane);
-    } else if (blockIdx.x - extBlocks < shadowBlocks) {
-        const uint32_t q = (blockIdx.x - extBlocks) * 64u + lane;
+    } else if (block - extBlocks < shadowBlocks) {
+        const uint32_t q = (block - extBlocks) * 64u + lane;
         const bool has = q < nShadow;
         if (has) {
-            const uint32_t p = pool.qShadow[q];
+            const uint32_t p = pool.qShadow[seg * pool.segCap + q];
             float4 ra = pool.rayA[p], rb = pool.rayB[p];
             const bool sticky = sv.hasGlass && (__float_as_uint(rb.w) & ST_GLASS_STICKY) != 0;
             if (sticky) { ra = pool.glassA[p]; rb = pool.glassB[p]; }
@@ -1351,7 +1372,14 @@ PoolDims pool_dims(const SceneView& sv, uint64_t P, uint64_t S)
 }
 
 // Lays the arrays of a Pool out in one block of device memory starting at `base` (null: only the size is computed).
-// Returns the bytes needed.  The per-step counters come last: counters[step][kPoolCounters].
+// Returns the bytes needed.  The per-step counters come last: counters[step][kCtrStride].
+// What the shade workgroups of one residue (mod kQueueSegs) of a batch of nPaths paths can append to their segment.
+inline uint32_t queue_segment_capacity(uint64_t nPaths)
+{
+    const uint64_t blocks = (nPaths + kShadeBlock - 1) / kShadeBlock;
+    return (uint32_t)((blocks + kQueueSegs - 1) / kQueueSegs * kShadeBlock);
+}
+
 size_t pool_carve(Pool& pool, char* base, const PoolDims& d)
 {
     size_t off = 0;
@@ -1371,12 +1399,13 @@ size_t pool_carve(Pool& pool, char* base, const PoolDims& d)
     pool.acc = (float4*)take(d.add ? P * 16 : 16); pool.accPend = (float4*)take(d.add ? P * 16 : 16);
     pool.sA = (float4*)take(S * 16); pool.sB = (float4*)take(S * 16); pool.sC = (float4*)take(S * 16);
     pool.sLive = (uint8_t*)take(S); pool.sHasVar = (uint8_t*)take(S);
-    pool.qA = (uint32_t*)take(P * 4); pool.qB = (uint32_t*)take(P * 4); pool.qShadow = (uint32_t*)take(P * 4);
+    const size_t Q = (size_t)kQueueSegs * queue_segment_capacity(d.P) * 4;   // (the segments' roundings: up to 256 entries each more than P)
+    pool.qA = (uint32_t*)take(Q); pool.qB = (uint32_t*)take(Q); pool.qShadow = (uint32_t*)take(Q);
     pool.qPhoton = (uint32_t*)take(d.photons ? P * 4 : 4);
     pool.qPhotonTail = (uint32_t*)take(d.photons ? P * 4 : 4);
     const size_t nC = d.caustics ? P * 16 : 16;
     pool.cHit = (float4*)take(nC); pool.cDir = (float4*)take(nC); pool.cThrColor = (float4*)take(nC); pool.cBase = (float4*)take(nC);
-    pool.counters = (uint32_t*)take((size_t)kMaxSteps * kPoolCounters * sizeof(uint32_t));
+    pool.counters = (uint32_t*)take((size_t)kMaxSteps * kCtrStride * sizeof(uint32_t));
     return off;
 }
 
@@ -1406,7 +1435,7 @@ struct StageTimer {
 struct LaneRun {
     hipStream_t stream = nullptr;
     Pool pool{};
-    uint32_t* hostCounters = nullptr;      // kMaxSteps * kPoolCounters words, pinned; null: never read back
+    uint32_t* hostCounters = nullptr;      // kMaxSteps * kCtrStride words, pinned; null: never read back
     hipEvent_t stepEv[4] = {nullptr, nullptr, nullptr, nullptr};
     unsigned long long* work = nullptr;    // device, 9 counters: the counting render
     StageTimer* timer = nullptr;           // the profiling render: events around every launch
@@ -1443,26 +1472,29 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
     size_t spanA = 0, spanB = 0;
 #define TB() do { if (ln.timer) RB_TRY(ln.timer->mark(ls, spanA)); } while (0)
 #define TE(stage) do { if (ln.timer) { RB_TRY(ln.timer->mark(ls, spanB)); ln.timer->spans.push_back(StageTimer::Span{stage, spanA, spanB}); } } while (0)
-    RB_TRY(hipMemsetAsync(pool.counters, 0, (size_t)maxSteps * kPoolCounters * sizeof(uint32_t), ls));
+    RB_TRY(hipMemsetAsync(pool.counters, 0, (size_t)maxSteps * kCtrStride * sizeof(uint32_t), ls));
     TB();
     if (mode == kTraceSingle) launch(primary_kernel<kTraceSingle>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
     else if (mode == kTraceInstances) launch(primary_kernel<kTraceInstances>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
     else launch(primary_kernel<kTraceLanes>, (nS + 63) / 64, 64, ls, sv, pool, cam, st, batch);
     TE(kStagePrimary);
     if (ln.work) launch(primary_count_kernel, (nS + 63) / 64, 64, ls, sv, cam, st, batch, ln.work);
-    uint32_t bound = nP;           // upper bound of the number of paths the next pass shades
+    pool.segCap = queue_segment_capacity(nP);
+    uint32_t bound = pool.segCap;  // upper bound of the number of paths of the longest queue segment the next pass shades
     uint32_t* qIn = pool.qA;
     uint32_t* qOut = pool.qB;
     int steps = 0;
     for (int step = 0; step < maxSteps; ++step) {
         if (ln.hostCounters && step >= 2) {
             RB_TRY(hipEventSynchronize(ln.stepEv[(step - 2) & 3]));
-            bound = ln.hostCounters[(size_t)(step - 2) * kPoolCounters];   // paths pass step - 1 shaded
+            const uint32_t* h = ln.hostCounters + (size_t)(step - 2) * kCtrStride;   // the paths pass step - 1 shaded, by segment
+            bound = 0;
+            for (uint32_t sg = 0; sg < kQueueSegs; ++sg) bound = std::max(bound, h[kCtrExt + sg * kCtrLine]);
             if (bound == 0) break;
         }
-        uint32_t* cnt = pool.counters + (size_t)step * kPoolCounters;
-        const uint32_t* cntIn = step ? cnt - kPoolCounters : cnt;
-        const uint32_t shadeBlocks = (bound + kShadeBlock - 1) / kShadeBlock;
+        uint32_t* cnt = pool.counters + (size_t)step * kCtrStride;
+        const uint32_t* cntIn = step ? cnt - kCtrStride : cnt;
+        const uint32_t shadeBlocks = step == 0 ? (nP + kShadeBlock - 1) / kShadeBlock : kQueueSegs * ((bound + kShadeBlock - 1) / kShadeBlock);
         TB();
         const ShadeArgs sa{sv, pool, st, batch, (const uint32_t*)qIn, nP, cntIn, qOut, cnt};
         if (rich) {
@@ -1474,20 +1506,21 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
         }
         TE(kStageShade);
         if (ln.hostCounters) {
-            RB_TRY(hipMemcpyAsync(ln.hostCounters + (size_t)step * kPoolCounters, cnt, kPoolCounters * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
+            RB_TRY(hipMemcpyAsync(ln.hostCounters + (size_t)step * kCtrStride, cnt, kCtrStride * sizeof(uint32_t), hipMemcpyDeviceToHost, ls));
             RB_TRY(hipEventRecord(ln.stepEv[step & 3], ls));
         }
         if (sv.pmMode != RTGPU_PM_NONE) {
             TB();
-            launch(photon_gather_stage_kernel, (bound + 63) / 64, 64, ls, sv, pool, cnt);
-            launch(photon_gather_tail_kernel, std::min(bound, tailCap), 64, ls, sv, pool, (const uint32_t*)cnt);
+            const uint32_t shaded = (uint32_t)std::min<uint64_t>((uint64_t)bound * kQueueSegs, nP);   // (the photon queue is one list)
+            launch(photon_gather_stage_kernel, (shaded + 63) / 64, 64, ls, sv, pool, cnt);
+            launch(photon_gather_tail_kernel, std::min(shaded, tailCap), 64, ls, sv, pool, (const uint32_t*)cnt);
             TE(kStageGather);
         }
-        // A shaded path leaves at most one ray behind -- an extension ray or a shadow ray -- so both queues together are at
-        // most `bound` long (two block counts rounded up: + 2); only a glass vertex can leave both (its own ray and the
-        // look along the direction it did not take), then each queue can be `bound` long.  Surplus workgroups find
+        // A shaded path leaves at most one ray behind -- an extension ray or a shadow ray -- so both queues of a segment
+        // together are at most `bound` long (two block counts rounded up: + 2); only a glass vertex can leave both (its own
+        // ray and the look along the direction it did not take), then each can be `bound` long.  Surplus workgroups find
         // nothing to do and leave, but their launches are not free.
-        const uint32_t traceBlocks = sv.hasGlass ? 2 * ((bound + 63) / 64) : (bound + 63) / 64 + 2;
+        const uint32_t traceBlocks = kQueueSegs * (sv.hasGlass ? 2 * ((bound + 63) / 64) : (bound + 63) / 64 + 2);
         TB();
         if (ln.work) launch(trace_stage_count_kernel, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt, ln.work);
         else if (mode == kTraceSingle) launch(trace_stage_kernel<kTraceSingle>, traceBlocks, 64, ls, sv, pool, (const uint32_t*)qOut, (const uint32_t*)cnt);
@@ -1513,9 +1546,12 @@ hipError_t run_batch(const SceneView& sv, LaneRun& ln, const rtgpu_camera& cam, 
         // ray statistics: every pass's counters have arrived once the last pass's have
         RB_TRY(hipEventSynchronize(ln.stepEv[(steps - 1) & 3]));
         for (int s2 = 0; s2 < steps; ++s2) {
-            const uint32_t* h = ln.hostCounters + (size_t)s2 * kPoolCounters;
-            ln.extension += h[0] - h[3];
-            ln.shadow += h[1];
+            const uint32_t* h = ln.hostCounters + (size_t)s2 * kCtrStride;
+            for (uint32_t sg = 0; sg < kQueueSegs; ++sg) {
+                ln.extension += h[kCtrExt + sg * kCtrLine];
+                ln.shadow += h[kCtrShadow + sg * kCtrLine];
+            }
+            ln.extension -= h[3];
         }
     }
 #undef TB
@@ -1615,7 +1651,7 @@ hipError_t ensure_lane(RenderCache::Lane& l, const PoolDims& dims, std::string& 
     if (!l.stream) EL_TRY(hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
     if (!l.done) EL_TRY(hipEventCreateWithFlags(&l.done, hipEventDisableTiming));
     for (hipEvent_t& ev : l.stepEv) if (!ev) EL_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-    if (!l.hostCounters) EL_TRY(hipHostMalloc((void**)&l.hostCounters, (size_t)kMaxSteps * kPoolCounters * sizeof(uint32_t)));
+    if (!l.hostCounters) EL_TRY(hipHostMalloc((void**)&l.hostCounters, (size_t)kMaxSteps * kCtrStride * sizeof(uint32_t)));
     if (!(l.dims == dims) || !l.mem) {
         Pool probe{};
         const size_t need = pool_carve(probe, nullptr, dims);
