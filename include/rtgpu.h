@@ -204,7 +204,7 @@ typedef enum rtgpu_jitter_mode {
 
 /* RenderSettings (renderer/Renderer.h:8-12) + the Tile (film/Tile.h) + FrameBuffer size. */
 typedef struct rtgpu_render_settings {
-    int32_t width, height;                       /* FrameBuffer resolution */
+    int32_t width, height;                       /* FrameBuffer resolution; width * height <= RTGPU_MAX_PIXELS */
     int32_t x_start, y_start, x_end, y_end;      /* half-open tile, film/Tile.h:19-23 */
     int32_t geometry_aa;                         /* geometryAAModifier (default 4) */
     int32_t material_aa;                         /* materialAAModifier (default 32); geometry_aa * material_aa, the paths of one
@@ -221,6 +221,9 @@ typedef struct rtgpu_render_settings {
 
 /* A batch of paths holds whole pixels, and a path's index inside its batch travels in 25 bits of a queue entry. */
 #define RTGPU_MAX_PATHS_PER_PIXEL (1 << 25)
+/* width * height of a frame (RTGPU_ERR_LIMIT beyond): pixel indices, padded to whole squares when a frame is shared out
+ * over devices, stay below 2^31, which the kernels' index arithmetic relies on. */
+#define RTGPU_MAX_PIXELS (1 << 30)
 
 typedef struct rtgpu_render_stats {
     uint64_t primary_rays;   /* Scene::traceRay calls from renderer/Renderer.cpp:161,170 */

@@ -932,6 +932,8 @@ static int check_settings(const rtgpu_render_settings* st)
     if (st->x_start > st->x_end || st->y_start > st->y_end) return fail(RTGPU_ERR_INVALID_ARGUMENT, "Invalid tile bounds"); // film/Tile.cpp:9-12
     if (st->x_start < 0 || st->y_start < 0 || st->x_end > st->width || st->y_end > st->height)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "tile outside the frame buffer");
+    if ((int64_t)st->width * st->height > (int64_t)RTGPU_MAX_PIXELS)
+        return fail(RTGPU_ERR_LIMIT, "width * height exceeds 2^30 pixels");
     if (st->geometry_aa < 1 || st->material_aa < 1 || st->max_path_length < 1)
         return fail(RTGPU_ERR_INVALID_ARGUMENT, "sample counts and path length must be >= 1");
     if ((int64_t)st->geometry_aa * st->material_aa > (int64_t)RTGPU_MAX_PATHS_PER_PIXEL)

@@ -39,12 +39,16 @@
 #include <thread>
 #include <vector>
 
+#include "rt_fastdiv.h"
 #include "rt_scene.h"
 #include "rt_shade_inl.h"
 #include "rt_steal_inl.h"
 #include "rt_photon_inl.h"
 #include "rt_wave_inl.h"
 
+#ifndef RT_SHADE_WAVES
+#define RT_SHADE_WAVES 5   // waves per SIMD of the shade kernels without glass / add / photon-map code
+#endif
 #ifndef RT_SHADE_BLOCK
 #define RT_SHADE_BLOCK 256
 #endif
@@ -188,6 +192,9 @@ struct Batch {
     // (squares that stick out of the tile keep their full T x T slots, the outside pixels are written as zeros).
     uint32_t tileSize, nRanks, rank, tilesX, nTiles;
     uint32_t sqrtM;       // (int)sqrt((double)material_aa): the stratification grid of a sample's first variance vertex
+    FastDiv divM, divG, divSqrtM;   // by material_aa, geometry_aa, sqrtM
+    FastDiv divTw;        // by the tile's width
+    FastDiv divTT, divT, divTilesX;   // tileSize > 0: by tileSize^2, tileSize, tilesX
 };
 
 
@@ -198,15 +205,17 @@ __device__ __forceinline__ uint32_t tile_pixel(const rtgpu_render_settings& st, 
 {
     if (b.tileSize == 0u) {
         const uint32_t tw = (uint32_t)(st.x_end - st.x_start);
-        x = st.x_start + (int)(idx % tw);
-        y = st.y_start + (int)(idx / tw);
+        const uint32_t row = fast_div(idx, b.divTw);
+        x = st.x_start + (int)(idx - row * tw);
+        y = st.y_start + (int)row;
         valid = true;
     } else {
         const uint32_t T = b.tileSize, tt = T * T;
-        const uint32_t j = idx / tt, w = idx % tt;
+        const uint32_t j = fast_div(idx, b.divTT), w = idx - j * tt;
         const uint32_t k = j * b.nRanks + b.rank;
-        x = st.x_start + (int)((k % b.tilesX) * T + w % T);
-        y = st.y_start + (int)((k / b.tilesX) * T + w / T);
+        const uint32_t ky = fast_div(k, b.divTilesX), wy = fast_div(w, b.divT);
+        x = st.x_start + (int)((k - ky * b.tilesX) * T + (w - wy * T));
+        y = st.y_start + (int)(ky * T + wy);
         valid = k < b.nTiles && x < st.x_end && y < st.y_end;
     }
     return (uint32_t)(y * st.width + x);
@@ -267,7 +276,7 @@ __global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rt
     const uint32_t s0 = blockIdx.x * 64u + lane;
     const bool inBatch = s0 < batch.nPixels * G;
     const uint32_t s = inBatch ? s0 : 0u;
-    const uint32_t pl = s / G, i = s % G;
+    const uint32_t pl = fast_div(s, batch.divG), i = s - pl * G;
     int x, y;
     bool valid;
     tile_pixel(st, batch, batch.pixelStart + pl, x, y, valid);
@@ -387,7 +396,7 @@ template <bool FIRST, bool RICH>
 // five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took 98-111 of its own
 // accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and lose, and so does
 // five for the RICH variants)
-__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : 5, RICH ? 4 : 5))) void shade_kernel(ShadeArgs)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : RT_SHADE_WAVES, RICH ? 4 : RT_SHADE_WAVES))) void shade_kernel(ShadeArgs)
 {
     // The arguments are read where they are used, through the kernel-argument segment's address, instead of through the
     // parameter: as a parameter every field the kernel uses is loaded into scalar registers at its entry and stays there,
@@ -418,17 +427,17 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     ShadeItem it;
     it.p = 0; it.pixel = 0; it.i = 0; it.j = 0;
     it.active = q < nIn;
-    if (FIRST && it.active) it.active = pool.sLive[q / M] != 0;
+    if (FIRST && it.active) it.active = pool.sLive[fast_div(q, batch.divM)] != 0;
     uint32_t vertexGuess = 0;
     if (it.active) {
         const uint32_t entry = FIRST ? q : qIn[seg * pool.segCap + q];
         it.p = entry & kQueuePathMask;
-        const uint32_t s0 = it.p / M;
-        it.j = it.p % M;
-        it.i = s0 % G;
+        const uint32_t s0 = fast_div(it.p, batch.divM), pl = fast_div(s0, batch.divG);
+        it.j = it.p - s0 * M;
+        it.i = s0 - pl * G;
         int px, py;
         bool pvalid;
-        it.pixel = tile_pixel(st, batch, batch.pixelStart + s0 / G, px, py, pvalid);
+        it.pixel = tile_pixel(st, batch, batch.pixelStart + pl, px, py, pvalid);
         vertexGuess = entry >> kQueuePathBits;   // the vertex the pass will sample (see the queue push below)
     }
     if (sv.shadeRegroup) it = shade_regroup<kShadeBlock>(sv, st.seed, M, it, vertexGuess);   // uniform branch
@@ -500,7 +509,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
     if (active) {
         SHADE_T0(2);
         const int maxLen = st.max_path_length;
-        const uint32_t s = p / M, j = it.j, i = it.i;
+        const uint32_t s = fast_div(p, batch.divM), j = it.j, i = it.i;
         const uint32_t pixel = it.pixel;
         const float4 ra = FIRST ? pool.sA[s] : blkA;
         const float4 rb = FIRST ? pool.sB[s] : blkB;
@@ -689,6 +698,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
             const int sampleCount = isFirstVar ? (int)M : 1;
             const int sampleI = isFirstVar ? (int)j : 0;
             const int sampleGrid = isFirstVar ? (int)batch.sqrtM : 1;   // (int)sqrt((double)sampleCount)
+            const int sampleY = isFirstVar ? (int)fast_div(j, batch.divSqrtM) : 0, sampleX = sampleI - sampleY * sampleGrid;   // the sample's cell of that grid
             passed = passed || curVar;
             if (passed) state |= ST_PASSED_VAR;
             if (curVar && j == 0) pool.sHasVar[s] = 1;
@@ -898,7 +908,7 @@ __global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RIC
                         SHADE_T0(4);
                         SHADE_STAT(6, !glossy);
                         SHADE_STAT(8, glossy);
-                        const NeeSample ns = nee_sample(sv, hitpoint, sampleI, sampleGrid, st.seed, rp, vk);
+                        const NeeSample ns = nee_sample(sv, hitpoint, sampleX, sampleY, sampleGrid, st.seed, rp, vk);
                         done = true;
                         completed = true;
                         result = rgb_mul(thr, addE);   // what the vertex is worth when the light is hidden
@@ -1633,6 +1643,10 @@ uint64_t call_pixels(const rtgpu_render_settings& st, const TileOrder* order, Ba
     const uint32_t tw = (uint32_t)(st.x_end - st.x_start), th = (uint32_t)(st.y_end - st.y_start);
     proto = Batch{};
     proto.sqrtM = (uint32_t)(int)std::sqrt((double)st.material_aa);
+    proto.divM = fast_div_make((uint32_t)st.material_aa);
+    proto.divG = fast_div_make((uint32_t)st.geometry_aa);
+    proto.divSqrtM = fast_div_make(proto.sqrtM);
+    proto.divTw = fast_div_make(tw);
     if (!order || order->tileSize == 0) return (uint64_t)tw * th;
     const uint32_t T = order->tileSize;
     proto.tileSize = T;
@@ -1640,6 +1654,9 @@ uint64_t call_pixels(const rtgpu_render_settings& st, const TileOrder* order, Ba
     proto.rank = order->rank;
     proto.tilesX = (tw + T - 1) / T;
     proto.nTiles = proto.tilesX * ((th + T - 1) / T);
+    proto.divTT = fast_div_make(T * T);
+    proto.divT = fast_div_make(T);
+    proto.divTilesX = fast_div_make(proto.tilesX);
     const uint32_t mine = proto.nTiles > order->rank ? (proto.nTiles - order->rank + order->nRanks - 1) / order->nRanks : 0u;
     return (uint64_t)mine * T * T;
 }

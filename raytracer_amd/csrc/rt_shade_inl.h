@@ -176,9 +176,10 @@ __device__ __forceinline__ F3 sample_steradian_sphere(F3 center, float angle, fl
 // NextEventEstimation::sample with neePointLight / neeAreaLight / neeDirectionalLight, material/NextEventEstimation.cpp:8-120,
 // and AreaLight::generateStratifiedJitteredRandomPoint, light/AreaLight.cpp:26-41.  The visibility
 // query itself is left to the shadow stage.
-// `nn` = (int)sqrt((double)sampleCount), the stratification grid of the area light (the caller has it per launch).
+// `nn` = (int)sqrt((double)sampleCount), the stratification grid of the area light, and (sampleX, sampleY) =
+// (sampleI % nn, sampleI / nn), the sample's cell (the caller has the divisor per launch).
 // `prefix` = rand_prefix(pixel, sample) of the path vertex.
-__device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleI, int nn,
+__device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint, int sampleX, int sampleY, int nn,
                                                 uint32_t seed, uint64_t prefix, uint32_t vertex)
 {
     NeeSample out;
@@ -213,7 +214,7 @@ __device__ __forceinline__ NeeSample nee_sample(const SceneView& sv, F3 hitpoint
         const F3 v2 = (b - a) / (float)nn;
         const float u = 1.0f - sqrtf(rand_unit_from(prefix, seed, vertex, DIM_AREA_U));
         const float v = (1.0f - u) * rand_unit_from(prefix, seed, vertex, DIM_AREA_V);
-        const int y = sampleI / nn, x = sampleI % nn;
+        const int y = sampleY, x = sampleX;
         const F3 lampPoint = (a + ((u + x) * v1)) + ((v + y) * v2);
         F3 toLamp = lampPoint - hitpoint;
         const float lampT = norm3(toLamp);

@@ -89,6 +89,10 @@ def test_argument_errors_without_a_gpu():
     st = abi.make_settings(16, 16, geometry_aa=1 << 13, material_aa=1 << 12)
     assert lib.rtgpu_generate_primary_device(C.byref(cam), C.byref(st), 0, None, None, None) == 1   # accepted; the null buffers are what fails
     assert lib.rtgpu_comm_set_timeout_ms(None, 5) == 1
+    # pixel indices stay below 2^31: frames of more than 2^30 pixels are refused
+    st = abi.make_settings(1 << 15, (1 << 15) + 1, tile=(0, 0, 16, 16))
+    assert lib.rtgpu_generate_primary_device(C.byref(cam), C.byref(st), 0, None, None, None) == 6
+    assert b"2^30" in lib.rtgpu_last_error()
 
 
 def test_packed_scene_validation():

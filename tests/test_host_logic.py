@@ -128,3 +128,18 @@ def test_quantised_decode_never_rejects_a_box_a_ray_passes_through(tmp_path, dis
     r = subprocess.run([exe, "20000", "3", str(distance)], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("ok:")
+
+
+def test_launch_uniform_division_is_exact(tmp_path):
+    """rt_fastdiv.h (one multiply and a shift with a host-prepared factor, used by the integrator's index arithmetic): equal to
+    the integer division for every numerator below 2^31 that was tried -- multiples of the divisor and their neighbours, the
+    ends of the range, random values -- for every divisor up to 70 000, powers of two and their neighbours, and 200 000 random
+    divisors."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "check_fastdiv")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I" + os.path.join(root, "raytracer_amd", "csrc"), "-o", exe,
+                    os.path.join(root, "tests", "native", "check_fastdiv.cpp")], check=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("ok:")
