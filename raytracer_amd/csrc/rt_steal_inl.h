@@ -4,7 +4,7 @@
 // 10-25x the average number of steps: with one lane per ray the slowest ray of a launch sets
 // the launch time while its 63 neighbour lanes -- and most of the chip -- idle.  Here a lane is a
 // *worker*: whenever some lanes of the wave have run out of work they take pending subtrees from
-// the bottom (oldest = largest) end of busy lanes' stacks, which live in LDS as
+// the top (newest = nearest) end of busy lanes' stacks, which live in LDS as
 // stack[entry][lane] and are therefore readable by every lane of the wave.  Several workers can
 // then be inside one ray's tree at once; they share the ray's best hit through an LDS word per
 // ray:
@@ -28,6 +28,12 @@
 
 namespace rt {
 
+// Which end of a busy lane's stack a thief takes from: 1 = the top (the nearest pending subtree: work the ray needs next,
+// so the thief and the victim close in on the hit together), 0 = the bottom (the farthest, largest subtree: fewer steal
+// rounds, but more of what is stolen is cut off later by a nearer hit).
+#ifndef RT_STEAL_TOP
+#define RT_STEAL_TOP 1
+#endif
 #ifndef RT_STEAL_STACK
 #define RT_STEAL_STACK 14
 #endif
@@ -69,6 +75,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                                                              StealLds<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
                                                              const int minIdle, const int leafPct)
 {
+    constexpr bool kStealTop = RT_STEAL_TOP != 0;
     const DevInstance& in = sv.inst[0];
     const uint32_t nodeBase = in.root, triBase = in.triBase;
     F3 o, d;
@@ -83,7 +90,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
 
     int owner = lane;          // the ray this worker is traversing for
     int cur = 0;               // >= 0: inner node; < 0: ~(first << 4 | count - 1), a leaf with `count` triangles left to test
-    int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp); thieves take from sb
+    int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp); thieves take entry sp - 1 (RT_STEAL_TOP) or sb
     bool busy = valid;
     float tlim = ANY ? tmax : INFINITY;
     float rtmax = tmax;        // any-hit: the limit of the ray this worker is traversing for
@@ -123,7 +130,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
 #endif
         // ---- steal phase -------------------------------------------------------------------------
         if (__popcll(idleMask) >= minIdle) {
-            const bool canGive = busy && sb < sp && sb < kStealStack;
+            const bool canGive = busy && sb < sp && (kStealTop ? sp <= kStealStack : sb < kStealStack);
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
@@ -136,7 +143,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                 if (lane == 0) { dsSteal += 1; dsStolen += nGive < nIdle ? nGive : nIdle; }
 #endif
                 const int v = L.giveList[thief ? ri : 0];
-                const int vsb = __shfl(sb, v, 64);
+                const int vsb = kStealTop ? __shfl(sp, v, 64) - 1 : __shfl(sb, v, 64);
                 const int vowner = __shfl(owner, v, 64);
                 const float vox = __shfl(o.x, v, 64), voy = __shfl(o.y, v, 64), voz = __shfl(o.z, v, 64);
                 const float vdx = __shfl(d.x, v, 64), vdy = __shfl(d.y, v, 64), vdz = __shfl(d.z, v, 64);
@@ -151,7 +158,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                     busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
-                if (canGive && rg < nIdle) ++sb;
+                if (canGive && rg < nIdle) { if (kStealTop) --sp; else ++sb; }
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -391,7 +398,9 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
         // ---- steal phase -------------------------------------------------------------------------
         if (__popcll(idleMask) >= minIdle) {
             if (busy && sentPos >= 0 && sb == sentPos) { ++sb; sentPos = -1; }   // a bottom sentinel has nothing to return to
-            const bool canGive = busy && sb < sp && sb < kStealStack;
+            constexpr bool kStealTop = RT_STEAL_TOP != 0;
+            // (from the top: not the sentinel itself -- the victim pops it next and returns to the top level)
+            const bool canGive = busy && sb < sp && (kStealTop ? sp <= kStealStack && sentPos != sp - 1 : sb < kStealStack);
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
@@ -401,7 +410,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 __builtin_amdgcn_wave_barrier();
                 const bool thief = !busy && ri < nGive;
                 const int v = L.giveList[thief ? ri : 0];
-                const int vsb = __shfl(sb, v, 64);
+                const int vsb = kStealTop ? __shfl(sp, v, 64) - 1 : __shfl(sb, v, 64);
                 const int vowner = __shfl(owner, v, 64);
                 const int vsent = __shfl(sentPos, v, 64);
                 const int vinMesh = __shfl((int)inMesh, v, 64);
@@ -433,7 +442,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
-                if (canGive && rg < nIdle) ++sb;
+                if (canGive && rg < nIdle) { if (kStealTop) --sp; else ++sb; }
                 __builtin_amdgcn_wave_barrier();
             }
         }
