@@ -28,12 +28,6 @@
 
 namespace rt {
 
-// Which end of a busy lane's stack a thief takes from: 1 = the top (the nearest pending subtree: work the ray needs next,
-// so the thief and the victim close in on the hit together), 0 = the bottom (the farthest, largest subtree: fewer steal
-// rounds, but more of what is stolen is cut off later by a nearer hit).
-#ifndef RT_STEAL_TOP
-#define RT_STEAL_TOP 1
-#endif
 #ifndef RT_STEAL_STACK
 #define RT_STEAL_STACK 14
 #endif
@@ -75,7 +69,6 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                                                              StealLds<COUNT>& L, const int lane, uint32_t& nBoxes, uint32_t& nTris,
                                                              const int minIdle, const int leafPct)
 {
-    constexpr bool kStealTop = RT_STEAL_TOP != 0;
     const DevInstance& in = sv.inst[0];
     const uint32_t nodeBase = in.root, triBase = in.triBase;
     F3 o, d;
@@ -90,7 +83,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
 
     int owner = lane;          // the ray this worker is traversing for
     int cur = 0;               // >= 0: inner node; < 0: ~(first << 4 | count - 1), a leaf with `count` triangles left to test
-    int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp); thieves take entry sp - 1 (RT_STEAL_TOP) or sb
+    int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp) (sb stays 0 here; the instanced walk drops a bottom sentinel); thieves take from the top
     bool busy = valid;
     float tlim = ANY ? tmax : INFINITY;
     float rtmax = tmax;        // any-hit: the limit of the ray this worker is traversing for
@@ -129,28 +122,37 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
         if (lane == 0) { dsOuter += 1; dsBusy += __popcll(busyMask); }
 #endif
         // ---- steal phase -------------------------------------------------------------------------
+        // Idle lanes take the top entries of busy lanes' stacks -- the nearest pending subtrees, the work those rays need
+        // next, so thief and victim close in on the hit together (taking the bottom, farthest entry instead needed fewer
+        // rounds, but a fifth of the boxes stolen that way were cut off later by a nearer hit).  A lane gives its top entry,
+        // and its second one too when idle lanes are left over.
         if (__popcll(idleMask) >= minIdle) {
-            const bool canGive = busy && sb < sp && (kStealTop ? sp <= kStealStack : sb < kStealStack);
+            const bool canGive = busy && sb < sp && sp <= kStealStack;
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
                 const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
+                const bool canGive2 = canGive && sp - sb >= 2;
+                const unsigned long long give2Mask = wave_ballot(canGive2);
+                const int rg2 = nGive + __popcll(give2Mask & ltMask), nGiveAll = nGive + __popcll(give2Mask);
                 if (canGive) L.giveList[rg] = lane;
+                if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;   // (bit 6: the second entry from the top)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool thief = !busy && ri < nGive;
+                const bool thief = !busy && ri < nGiveAll;
 #ifdef RT_DEV_STATS
-                if (lane == 0) { dsSteal += 1; dsStolen += nGive < nIdle ? nGive : nIdle; }
+                if (lane == 0) { dsSteal += 1; dsStolen += nGiveAll < nIdle ? nGiveAll : nIdle; }
 #endif
-                const int v = L.giveList[thief ? ri : 0];
-                const int vsb = kStealTop ? __shfl(sp, v, 64) - 1 : __shfl(sb, v, 64);
+                const int ge = L.giveList[thief ? ri : 0];
+                const int v = ge & 63;
+                const int ventry = __shfl(sp, v, 64) - 1 - (ge >> 6);
                 const int vowner = __shfl(owner, v, 64);
                 const float vox = __shfl(o.x, v, 64), voy = __shfl(o.y, v, 64), voz = __shfl(o.z, v, 64);
                 const float vdx = __shfl(d.x, v, 64), vdy = __shfl(d.y, v, 64), vdz = __shfl(d.z, v, 64);
                 const float vix = __shfl(inv.x, v, 64), viy = __shfl(inv.y, v, 64), viz = __shfl(inv.z, v, 64);
                 const float vtmax = __shfl(rtmax, v, 64);
                 if (thief) {
-                    cur = L.stack[vsb][v];
+                    cur = L.stack[ventry][v];
                     owner = vowner;
                     o = f3(vox, voy, voz); d = f3(vdx, vdy, vdz); inv = f3(vix, viy, viz);
                     rtmax = vtmax;
@@ -158,7 +160,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                     busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
-                if (canGive && rg < nIdle) { if (kStealTop) --sp; else ++sb; }
+                sp -= (canGive && rg < nIdle ? 1 : 0) + (canGive2 && rg2 < nIdle ? 1 : 0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
@@ -330,7 +332,8 @@ __device__ __forceinline__ TraceResult trace_wave_steal(const SceneView& sv, boo
 // A stolen entry is of the kind its position says: below the victim's sentinel it is a top-level
 // subtree (the thief takes the world ray), above it a subtree of the victim's current instance
 // (the thief takes the victim's object-space ray and instance).  A sentinel at the very bottom
-// of a stack has nothing to return to and is dropped, so the bottom entry can always be given.
+// of a stack has nothing to return to and is dropped.  Thieves take the top entry (see trace_wave_steal_walk) unless it is
+// the sentinel.
 //
 // best[ray] = t bits << 32 | key, key = keyBase[instance] + caller's triangle index with keyBase
 // the running sum of the instances' triangle counts: keys order like (instance, triangle index),
@@ -398,9 +401,8 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
         // ---- steal phase -------------------------------------------------------------------------
         if (__popcll(idleMask) >= minIdle) {
             if (busy && sentPos >= 0 && sb == sentPos) { ++sb; sentPos = -1; }   // a bottom sentinel has nothing to return to
-            constexpr bool kStealTop = RT_STEAL_TOP != 0;
-            // (from the top: not the sentinel itself -- the victim pops it next and returns to the top level)
-            const bool canGive = busy && sb < sp && (kStealTop ? sp <= kStealStack && sentPos != sp - 1 : sb < kStealStack);
+            // (the top entry, but not the sentinel itself -- the victim pops that next and returns to the top level)
+            const bool canGive = busy && sb < sp && sp <= kStealStack && sentPos != sp - 1;
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
@@ -410,7 +412,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 __builtin_amdgcn_wave_barrier();
                 const bool thief = !busy && ri < nGive;
                 const int v = L.giveList[thief ? ri : 0];
-                const int vsb = kStealTop ? __shfl(sp, v, 64) - 1 : __shfl(sb, v, 64);
+                const int vsb = __shfl(sp, v, 64) - 1;
                 const int vowner = __shfl(owner, v, 64);
                 const int vsent = __shfl(sentPos, v, 64);
                 const int vinMesh = __shfl((int)inMesh, v, 64);
@@ -442,7 +444,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
-                if (canGive && rg < nIdle) { if (kStealTop) --sp; else ++sb; }
+                if (canGive && rg < nIdle) --sp;
                 __builtin_amdgcn_wave_barrier();
             }
         }
