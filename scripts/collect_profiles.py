@@ -23,11 +23,16 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
+def newest(pattern):
+    """Files matching `pattern`, the most recently written first (a directory that was profiled twice holds both runs)."""
+    return sorted(glob.glob(pattern), key=os.path.getmtime, reverse=True)
+
+
 def counters(dirs, kernel, split=None):
     """Sums (per run) or lists (split = launches per group) the counter values of `kernel` over the runs in `dirs`."""
     out = {}
     for d in dirs:
-        files = glob.glob(os.path.join(d, "*", "*_counter_collection.csv"))
+        files = newest(os.path.join(d, "*", "*_counter_collection.csv"))
         if not files:
             continue
         acc = collections.defaultdict(list)
@@ -88,7 +93,7 @@ def main():
                                         "(--steps 3 --warmup 1 for the trace, --steps 1 --warmup 0 for counters)",
                             "configs[1]": "rocprofv3 [...] -- python3 scripts/prof_c2.py (6 launches on primary rays, then 6 on bounce rays)"}}
     # ---- headline frame: trace_stage_kernel, per frame
-    stats = glob.glob(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
+    stats = newest(os.path.join(src, "trace", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats, os.path.join(dst, tag + "_bench_kernel_stats.csv"))
     kt = kernel_time(stats, "trace_stage_kernel")
     frames_traced = 4   # --steps 3 --warmup 1
@@ -102,9 +107,9 @@ def main():
             head["hbm_bytes_per_frame"] = head.pop("hbm_bytes")
     summary["headline_trace_stage"] = head
     # ---- configs[1]: the closest-hit kernel, launches 0..5 primary rays, 6..11 bounce rays
-    stats2 = glob.glob(os.path.join(src, "trace_c2", "*", "*_kernel_stats.csv"))[0]
+    stats2 = newest(os.path.join(src, "trace_c2", "*", "*_kernel_stats.csv"))[0]
     shutil.copy(stats2, os.path.join(dst, tag + "_c2_kernel_stats.csv"))
-    trace2 = glob.glob(os.path.join(src, "trace_c2", "*", "*_kernel_trace.csv"))[0]
+    trace2 = newest(os.path.join(src, "trace_c2", "*", "*_kernel_trace.csv"))[0]
     durs = [int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in csv.DictReader(open(trace2)) if "trace_closest_steal_kernel" in r["Kernel_Name"]]
     lists = counters(sorted(glob.glob(os.path.join(src, "pmc_c2_*"))), "trace_closest_steal_kernel")
     for name, sl in (("c2_primary", slice(1, 6)), ("c2_bounce", slice(7, 12))):
@@ -116,7 +121,7 @@ def main():
             e["hbm_bytes_per_launch"] = e.pop("hbm_bytes")
         summary[name] = e
     # ---- configs[4]: trace_stage_kernel over two frames of the 49.8 M-triangle cluster
-    st5 = glob.glob(os.path.join(src, "trace_c5", "*", "*_kernel_stats.csv"))
+    st5 = newest(os.path.join(src, "trace_c5", "*", "*_kernel_stats.csv"))
     if st5:
         shutil.copy(st5[0], os.path.join(dst, tag + "_c5_kernel_stats.csv"))
         kt5 = kernel_time(st5[0], "trace_stage_kernel")
@@ -131,7 +136,7 @@ def main():
         summary["commands"]["configs[4]"] = "RTGPU_RENDER_LANES=1 rocprofv3 [...] -- python3 scripts/prof_c5.py (two frames; figures per frame)"
     # ---- configs[2] / configs[3]: trace_stage_kernel over frames of the interior scene (two 1080p frames / one 4K frame)
     for key, name, frames in (("interior_1080p_trace_stage", "i1080", 2.0), ("interior_4k_trace_stage", "i4k", 1.0)):
-        sti = glob.glob(os.path.join(src, "trace_" + name, "*", "*_kernel_stats.csv"))
+        sti = newest(os.path.join(src, "trace_" + name, "*", "*_kernel_stats.csv"))
         if not sti:
             continue
         shutil.copy(sti[0], os.path.join(dst, tag + "_" + name + "_kernel_stats.csv"))

@@ -6,6 +6,7 @@
 set -o pipefail
 tag=${1:-r02}
 out=$PWD/gpurun_out/prof_$tag
+rm -rf "$out"
 mkdir -p "$out"
 export TMPDIR=/tmp
 export RTGPU_RENDER_LANES=1

@@ -4,6 +4,7 @@
 set -o pipefail
 tag=${1:-shade}
 out=$PWD/gpurun_out/prof_$tag
+rm -rf "$out"
 mkdir -p "$out"
 export TMPDIR=/tmp
 export RTGPU_RENDER_LANES=1
