@@ -762,7 +762,9 @@ static int scene_create(const rtgpu_scene_desc* desc, rtgpu_scene** out_scene)
     }
     // a wave steals once 16 of its lanes are out of work: with the 64-byte nodes the kernels are bound by instruction issue and
     // fewer, fuller stealing rounds pay (1 / 4 / 8 / 16: bounce rays 5078 / 5122 / 5072 / 5187 Mrays/s, any-hit 5331 / 5433 / 5437 / 5605)
-    v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : 16;
+    // A scene that does not fit the 256 MB Infinity Cache waits for memory, and a round's LDS round trips add to every wait:
+    // 24 there (49.8 M triangles, trace stage of the path-traced frame 8 / 16 / 24 / 32: 7.57 / 7.35 / 7.04 / 7.06 ms).
+    v.stealMinIdle = std::getenv("RTGPU_STEAL_MIN_IDLE") ? std::atoi(std::getenv("RTGPU_STEAL_MIN_IDLE")) : (bytes > (256ull << 20) ? 24 : 16);
     v.gatherBudget = std::getenv("RTGPU_GATHER_BUDGET") ? (uint32_t)std::strtoul(std::getenv("RTGPU_GATHER_BUDGET"), nullptr, 10) : 192u;
     v.skipBlackShadow = std::getenv("RTGPU_SKIP_BLACK_SHADOW") ? std::atoi(std::getenv("RTGPU_SKIP_BLACK_SHADOW")) : 1;
     v.shadeRegroup = std::getenv("RTGPU_SHADE_REGROUP") ? std::atoi(std::getenv("RTGPU_SHADE_REGROUP")) : 1;
