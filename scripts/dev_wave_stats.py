@@ -51,3 +51,17 @@ o = d_o.cpu().numpy(); d = d_d.cpu().numpy()
 stats(g, o, d, "primary rows", True)
 ro, rd = scenes.random_rays(2_000_000, (-1.6, -1.6, -1.6), (1.6, 1.6, 1.6), seed=2)
 stats(g, ro, rd, "random incoherent")
+# diffuse-bounce rays from the primary hit points (as bench.py's configs[1] makes them)
+hits = torch.empty((n, 5), dtype=torch.int32, device=dev)
+g.trace_rays_device(d_o, d_d, n, hits, stream); torch.cuda.synchronize()
+h = hits.cpu().numpy().view(np.uint32)
+hit = h[:, 2] != 0xFFFFFFFF
+t = h[hit, 0].view(np.float32)
+hp = (o[hit] + d[hit] * t[:, None]).astype(np.float32)
+rng = np.random.RandomState(1)
+so = np.tile(hp, (int(np.ceil(n / len(hp))), 1))[:n]
+nn = so / np.linalg.norm(so, axis=1, keepdims=True)
+so = (so + nn * 1e-3).astype(np.float32)
+sd = rng.normal(size=so.shape); sd /= np.linalg.norm(sd, axis=1, keepdims=True)
+sd[(sd * nn).sum(1) < 0] *= -1
+stats(g, so, sd.astype(np.float32), "bounce rays")
