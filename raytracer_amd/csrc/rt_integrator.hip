@@ -267,8 +267,11 @@ __device__ __forceinline__ void queue_push1(uint32_t* q, uint32_t* c, bool pred,
 }
 
 // ---- primary ---------------------------------------------------------------------------------
+#ifndef RT_PRIMARY_WAVES
+#define RT_PRIMARY_WAVES 7   // waves per SIMD of the one-mesh primary kernel (72 VGPRs; left alone it takes 84 = 5 waves: primary stage 2.24 -> 2.14 ms per 1080p frame)
+#endif
 template <int MODE>
-__global__ __launch_bounds__(64) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(MODE == kTraceSingle ? RT_PRIMARY_WAVES : 1))) void primary_kernel(SceneView sv, Pool pool, rtgpu_camera cam, rtgpu_render_settings st, Batch batch)
 {
     __shared__ typename TraceLds<MODE>::type lds;
     const int lane = threadIdx.x;
