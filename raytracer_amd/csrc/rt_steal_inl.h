@@ -91,7 +91,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
     int spill[kStackDepth - kStealStack];
     const unsigned long long ltMask = (1ull << lane) - 1ull;
 #ifdef RT_DEV_STATS
-    float dsOuter = 0, dsSteal = 0, dsNodeIt = 0, dsLeafIt = 0, dsBusy = 0, dsStolen = 0;
+    float dsOuter = 0, dsSteal = 0, dsNodeIt = 0, dsLeafIt = 0, dsBusy = 0, dsStolen = 0, dsHi56 = 0, dsHi48 = 0, dsLo32 = 0, dsLo16 = 0;
     const uint32_t dsT0 = (uint32_t)wall_clock64();
 #endif
 
@@ -119,7 +119,13 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
         if (busyMask == 0ull) break;
         const unsigned long long idleMask = ~busyMask;
 #ifdef RT_DEV_STATS
-        if (lane == 0) { dsOuter += 1; dsBusy += __popcll(busyMask); }
+        if (lane == 0) {
+            dsOuter += 1; dsBusy += __popcll(busyMask);
+            if (__popcll(busyMask) >= 56) dsHi56 += 1;
+            if (__popcll(busyMask) >= 48) dsHi48 += 1;
+            if (__popcll(busyMask) < 32) dsLo32 += 1;
+            if (__popcll(busyMask) < 16) dsLo16 += 1;
+        }
 #endif
         // ---- steal phase -------------------------------------------------------------------------
         // Idle lanes take the top entries of busy lanes' stacks -- the nearest pending subtrees, the work those rays need
@@ -294,15 +300,17 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
 #ifdef RT_DEV_STATS
     // developer build: lanes 0..7 report wave-level schedule statistics in place of their tri counts
     if (COUNT) {
-        __shared__ float ds[8];
-        if (lane < 8) ds[lane] = 0.0f;
+        __shared__ float ds[12];
+        if (lane < 12) ds[lane] = 0.0f;
         __builtin_amdgcn_wave_barrier();
         atomicAdd(&ds[0], dsOuter); atomicAdd(&ds[1], dsSteal); atomicAdd(&ds[2], dsNodeIt);
         atomicAdd(&ds[3], dsLeafIt); atomicAdd(&ds[4], dsBusy); atomicAdd(&ds[5], dsStolen);
+        atomicAdd(&ds[8], dsHi56); atomicAdd(&ds[9], dsHi48); atomicAdd(&ds[10], dsLo32); atomicAdd(&ds[11], dsLo16);
         __builtin_amdgcn_wave_barrier();
         if (lane < 6) nTris = (uint32_t)(ds[lane] + 0.5f);
         if (lane == 6) nTris = dsT0;
         if (lane == 7) nTris = (uint32_t)wall_clock64();
+        if (lane >= 8 && lane < 12) nTris = (uint32_t)(ds[lane] + 0.5f);   // iterations with >= 56, >= 48, < 32, < 16 busy lanes
     }
 #endif
     return r;

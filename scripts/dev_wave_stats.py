@@ -25,10 +25,12 @@ def stats(g, o, d, label, show_timeline=False):
     w = c[ray].reshape(n // 64, 64, 2)
     nw = n // 64
     boxes = w[:, :, 0].sum()
-    tris = w[:, 8:, 1].sum() * 64 / 56
+    tris = w[:, 12:, 1].sum() * 64 / 52
+    hi56, hi48, lo32, lo16 = w[:, 8:12, 1].sum(0).astype(np.float64)
     outer, steal, nodeit, leafit, busy, stolen = w[:, :6, 1].sum(0).astype(np.float64)
     print(f"{label}: rays={n} waves={nw} boxes/ray={boxes/n:.2f} tris/ray~{tris/n:.2f}")
     print(f"   per wave: iterations={outer/nw:.1f} steal rounds={steal/nw:.1f} stolen entries={stolen/nw:.1f} node steps={nodeit/nw:.1f} leaf steps={leafit/nw:.1f} busy lanes per iteration={busy/max(outer,1):.1f}")
+    print(f"   share of iterations with >= 56 busy lanes {hi56/outer:.2f}, >= 48: {hi48/outer:.2f}, < 32: {lo32/outer:.2f}, < 16: {lo16/outer:.2f}")
     print(f"   boxes per node step={boxes/nodeit:.1f} (of 256) triangles per leaf step~{tris/leafit:.1f} (of 64)")
     t0 = w[:, 6, 1]; t1 = w[:, 7, 1]
     base = t0.min()
