@@ -432,6 +432,23 @@ def test_render_statistically_matches_other_seeds():
     assert np.mean(z < 4) > 0.97
 
 
+@pytest.mark.parametrize("W,H,G,M,tile", [(1, 1, 1, 1, None), (7, 5, 3, 5, None), (13, 3, 1, 7, (2, 1, 11, 3)), (5, 9, 6, 1, None), (3, 2, 2, 129, None)])
+def test_awkward_frame_and_sample_counts_match_oracle(W, H, G, M, tile):
+    """Frames, tiles and sample counts that are no multiple of anything the kernels are cut by (a workgroup's 256 paths, the
+    eight queue segments, a wave's 64 rays; divisors that are no powers of two in the index arithmetic): the oracle's image
+    at matched random numbers, to rounding."""
+    sc, cam_m, yfov = scenes.box_scene(with_mirror=True)
+    cam = api.camera_from_transform(scenes.x_fov_degrees(yfov, W / H), cam_m)
+    st = abi.make_settings(W, H, geometry_aa=G, material_aa=M, seed=5, tile=tile)
+    ref, rstats = oracle.OracleScene(sc).render(cam, st)
+    with api.Scene(sc) as g:
+        img, stats = api.Renderer().render(g, cam, st)
+    x0, y0, x1, y1 = tile if tile else (0, 0, W, H)
+    assert np.isfinite(img).all()
+    assert rel_rmse(img[y0:y1, x0:x1], ref[y0:y1, x0:x1]) <= 1e-4
+    assert stats.primary_rays == rstats.primary_rays == (x1 - x0) * (y1 - y0) * G
+
+
 def test_render_tile_and_batching_do_not_change_pixels():
     sc, cam_m, yfov = scenes.box_scene()
     W, H = 40, 30
