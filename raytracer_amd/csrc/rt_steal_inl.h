@@ -415,12 +415,18 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
             if (giveMask != 0ull) {
                 const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
                 const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
+                // (a second entry from the top when idle lanes are left over, as in trace_wave_steal_walk -- unless it is the sentinel)
+                const bool canGive2 = canGive && sp - sb >= 2 && sentPos != sp - 2;
+                const unsigned long long give2Mask = wave_ballot(canGive2);
+                const int rg2 = nGive + __popcll(give2Mask & ltMask), nGiveAll = nGive + __popcll(give2Mask);
                 if (canGive) L.giveList[rg] = lane;
+                if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool thief = !busy && ri < nGive;
-                const int v = L.giveList[thief ? ri : 0];
-                const int vsb = __shfl(sp, v, 64) - 1;
+                const bool thief = !busy && ri < nGiveAll;
+                const int ge = L.giveList[thief ? ri : 0];
+                const int v = ge & 63;
+                const int vsb = __shfl(sp, v, 64) - 1 - (ge >> 6);
                 const int vowner = __shfl(owner, v, 64);
                 const int vsent = __shfl(sentPos, v, 64);
                 const int vinMesh = __shfl((int)inMesh, v, 64);
@@ -452,7 +458,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
-                if (canGive && rg < nIdle) --sp;
+                sp -= (canGive && rg < nIdle ? 1 : 0) + (canGive2 && rg2 < nIdle ? 1 : 0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
