@@ -89,7 +89,6 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
     float rtmax = tmax;        // any-hit: the limit of the ray this worker is traversing for
     uint32_t wb = 0, wt = 0;
     int spill[kStackDepth - kStealStack];
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
 #ifdef RT_DEV_STATS
     float dsOuter = 0, dsSteal = 0, dsNodeIt = 0, dsLeafIt = 0, dsBusy = 0, dsStolen = 0, dsHi56 = 0, dsHi48 = 0, dsLo32 = 0, dsLo16 = 0;
     const uint32_t dsT0 = (uint32_t)wall_clock64();
@@ -136,11 +135,11 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
             const bool canGive = busy && sb < sp && sp <= kStealStack;
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
-                const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
+                const int rg = lanes_below(giveMask), ri = lanes_below(idleMask);
                 const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
                 const bool canGive2 = canGive && sp - sb >= 2;
                 const unsigned long long give2Mask = wave_ballot(canGive2);
-                const int rg2 = nGive + __popcll(give2Mask & ltMask), nGiveAll = nGive + __popcll(give2Mask);
+                const int rg2 = nGive + lanes_below(give2Mask), nGiveAll = nGive + __popcll(give2Mask);
                 if (canGive) L.giveList[rg] = lane;
                 if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;   // (bit 6: the second entry from the top)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -379,7 +378,6 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
     float rtmax = tmax;
     uint32_t wb = 0, wt = 0;
     int spill[kStackDepth - kStealStack];
-    const unsigned long long ltMask = (1ull << lane) - 1ull;
 
     auto push = [&](int v) {
         if (sp < kStealStack) L.stack[sp][lane] = v;
@@ -413,12 +411,12 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
             const bool canGive = busy && sb < sp && sp <= kStealStack && sentPos != sp - 1;
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
-                const int rg = __popcll(giveMask & ltMask), ri = __popcll(idleMask & ltMask);
+                const int rg = lanes_below(giveMask), ri = lanes_below(idleMask);
                 const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
                 // (a second entry from the top when idle lanes are left over, as in trace_wave_steal_walk -- unless it is the sentinel)
                 const bool canGive2 = canGive && sp - sb >= 2 && sentPos != sp - 2;
                 const unsigned long long give2Mask = wave_ballot(canGive2);
-                const int rg2 = nGive + __popcll(give2Mask & ltMask), nGiveAll = nGive + __popcll(give2Mask);
+                const int rg2 = nGive + lanes_below(give2Mask), nGiveAll = nGive + __popcll(give2Mask);
                 if (canGive) L.giveList[rg] = lane;
                 if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
