@@ -81,10 +81,14 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
     L.paySlot[lane] = kInvalid;
     if constexpr (COUNT) { L.cnt[0][lane] = 0; L.cnt[1][lane] = 0; }
 
+    // A lane's state is `cur` alone: >= 0 an inner node; kIdle (the most negative number) no work; any other negative number
+    // ~(first << 4 | count - 1), a leaf with `count` triangles left to test.  Every vote of the loop below is then ONE
+    // compare on a register (a vote on a condition put together from several costs two more vector instructions each: the
+    // compiler turns the combined lane mask into 0 / 1 per lane and compares that again).
+    constexpr int kIdle = (int)0x80000000;
     int owner = lane;          // the ray this worker is traversing for
-    int cur = 0;               // >= 0: inner node; < 0: ~(first << 4 | count - 1), a leaf with `count` triangles left to test
+    int cur = valid ? 0 : kIdle;
     int sp = 0, sb = 0;        // this lane's stack holds entries [sb, sp) (sb stays 0 here; the instanced walk drops a bottom sentinel); thieves take from the top
-    bool busy = valid;
     float tlim = ANY ? tmax : INFINITY;
     float rtmax = tmax;        // any-hit: the limit of the ray this worker is traversing for
     uint32_t wb = 0, wt = 0;
@@ -114,7 +118,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
     // the other kind wait, so the kind is chosen per iteration: node steps as long as few lanes
     // wait at leaves.
     for (;;) {
-        const unsigned long long busyMask = wave_ballot(busy);
+        const unsigned long long busyMask = wave_ballot(cur != kIdle);
         if (busyMask == 0ull) break;
         const unsigned long long idleMask = ~busyMask;
 #ifdef RT_DEV_STATS
@@ -132,19 +136,19 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
         // rounds, but a fifth of the boxes stolen that way were cut off later by a nearer hit).  A lane gives its top entry,
         // and its second one too when idle lanes are left over.
         if (__popcll(idleMask) >= minIdle) {
-            const bool canGive = busy && sb < sp && sp <= kStealStack;
+            const bool canGive = (uint32_t)(sp - 1) < (uint32_t)kStealStack;   // 0 < sp <= kStealStack (sb stays 0 in this walk; an idle lane's sp is 0)
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = lanes_below(giveMask), ri = lanes_below(idleMask);
                 const int nGive = __popcll(giveMask), nIdle = __popcll(idleMask);
-                const bool canGive2 = canGive && sp - sb >= 2;
+                const bool canGive2 = (uint32_t)(sp - 2) < (uint32_t)(kStealStack - 1);   // 2 <= sp <= kStealStack
                 const unsigned long long give2Mask = wave_ballot(canGive2);
                 const int rg2 = nGive + lanes_below(give2Mask), nGiveAll = nGive + __popcll(give2Mask);
                 if (canGive) L.giveList[rg] = lane;
                 if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;   // (bit 6: the second entry from the top)
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool thief = !busy && ri < nGiveAll;
+                const bool thief = cur == kIdle && ri < nGiveAll;
 #ifdef RT_DEV_STATS
                 if (lane == 0) { dsSteal += 1; dsStolen += nGiveAll < nIdle ? nGiveAll : nIdle; }
 #endif
@@ -162,22 +166,21 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
                     o = f3(vox, voy, voz); d = f3(vdx, vdy, vdz); inv = f3(vix, viy, viz);
                     rtmax = vtmax;
                     sp = 0; sb = 0;
-                    busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
                 sp -= (canGive && rg < nIdle ? 1 : 0) + (canGive2 && rg2 < nIdle ? 1 : 0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        const unsigned long long nowBusy = wave_ballot(busy);
-        const unsigned long long nodeMask = wave_ballot(busy && cur >= 0);
+        const unsigned long long nowBusy = wave_ballot(cur != kIdle);
+        const unsigned long long nodeMask = wave_ballot(cur >= 0);
         const int nBusy = __popcll(nowBusy), nNode = __popcll(nodeMask);
         const bool nodeStep = nNode > 0 && (nBusy - nNode) * 128 < leafPct * nBusy;
         const bool deep = wave_ballot(sp >= kStealStack - 2) != 0ull;   // a node step may push three entries
         bool done = false;
         if (nodeStep) {
             // ---- inner node ------------------------------------------------------------------------
-            if (busy && cur >= 0) {
+            if (cur >= 0) {
                 // another worker of the same ray may have found a closer hit since this lane's last leaf
                 // (read before the node is asked for, so that the LDS round trip runs under the memory latency)
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
@@ -212,13 +215,14 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
             // A lane at a leaf offers up to four of its triangles; offers are numbered across the wave (prefix
             // counts from three ballots) and written to a list, and lane k tests offer k with the offering
             // lane's ray.  Results meet in best[], so who tests what does not matter.
-            const bool atLeaf = busy && cur < 0;
+            const bool atLeaf = (uint32_t)cur > (uint32_t)kIdle;   // negative, but not kIdle
             const uint32_t leaf = (uint32_t)(~cur);
             const int left = (int)(leaf & 15u) + 1;
             const int want = atLeaf ? (left < 4 ? left : 4) : 0;
+            const int wantBits = atLeaf ? want - 1 : 0;   // offers = 1 + bit 0 + 2 x bit 1
             const unsigned long long m0 = wave_ballot(atLeaf);
-            const unsigned long long m1 = wave_ballot(atLeaf && ((want - 1) & 1) != 0);
-            const unsigned long long m2 = wave_ballot(atLeaf && ((want - 1) & 2) != 0);
+            const unsigned long long m1 = wave_ballot((wantBits & 1) != 0);
+            const unsigned long long m2 = wave_ballot((wantBits & 2) != 0);
             const int pre = lanes_below(m0) + lanes_below(m1) + 2 * lanes_below(m2);
             const int total = __popcll(m0) + __popcll(m1) + 2 * __popcll(m2);
             int served = 64 - pre;
@@ -274,7 +278,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_walk(const SceneView& sv
             }
         }
         if (done) {
-            busy = false;
+            cur = kIdle;
             sp = 0; sb = 0;
             if constexpr (COUNT) { atomicAdd(&L.cnt[0][owner], wb); atomicAdd(&L.cnt[1][owner], wt); wb = 0; wt = 0; }
         }
