@@ -374,10 +374,10 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
     uint32_t nodeBase = sv.topRoot, triBase = 0, curInst = 0, keyBase = 0;
     bool inMesh = false;
     int sentPos = -1;          // stack index of the sentinel, -1: none (nothing to return to)
+    constexpr int kIdle = (int)0x80000000;   // a lane without work (see trace_wave_steal_walk: votes on `cur` are single compares)
     int owner = lane;
-    int cur = 0;
+    int cur = valid ? 0 : kIdle;
     int sp = 0, sb = 0;
-    bool busy = valid;
     float tlim = ANY ? tmax : INFINITY;
     float rtmax = tmax;
     uint32_t wb = 0, wt = 0;
@@ -405,14 +405,14 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
     };
 
     for (;;) {
-        const unsigned long long busyMask = wave_ballot(busy);
+        const unsigned long long busyMask = wave_ballot(cur != kIdle);
         if (busyMask == 0ull) break;
         const unsigned long long idleMask = ~busyMask;
         // ---- steal phase -------------------------------------------------------------------------
         if (__popcll(idleMask) >= minIdle) {
-            if (busy && sentPos >= 0 && sb == sentPos) { ++sb; sentPos = -1; }   // a bottom sentinel has nothing to return to
+            if (sentPos >= 0 && sb == sentPos) { ++sb; sentPos = -1; }   // a bottom sentinel has nothing to return to
             // (the top entry, but not the sentinel itself -- the victim pops that next and returns to the top level)
-            const bool canGive = busy && sb < sp && sp <= kStealStack && sentPos != sp - 1;
+            const bool canGive = sb < sp && sp <= kStealStack && sentPos != sp - 1;   // (an idle lane's stack is empty)
             const unsigned long long giveMask = wave_ballot(canGive);
             if (giveMask != 0ull) {
                 const int rg = lanes_below(giveMask), ri = lanes_below(idleMask);
@@ -425,7 +425,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                 if (canGive2 && rg2 < 64) L.giveList[rg2] = lane | 64;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                 __builtin_amdgcn_wave_barrier();
-                const bool thief = !busy && ri < nGiveAll;
+                const bool thief = cur == kIdle && ri < nGiveAll;
                 const int ge = L.giveList[thief ? ri : 0];
                 const int v = ge & 63;
                 const int vsb = __shfl(sp, v, 64) - 1 - (ge >> 6);
@@ -457,21 +457,20 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
                     sentPos = -1;
                     rtmax = vtmax;
                     sp = 0; sb = 0;
-                    busy = true;
                     tlim = __uint_as_float((uint32_t)(L.best[owner] >> 32));
                 }
                 sp -= (canGive && rg < nIdle ? 1 : 0) + (canGive2 && rg2 < nIdle ? 1 : 0);
                 __builtin_amdgcn_wave_barrier();
             }
         }
-        const unsigned long long nowBusy = wave_ballot(busy);
-        const unsigned long long nodeMask = wave_ballot(busy && cur >= 0);
+        const unsigned long long nowBusy = wave_ballot(cur != kIdle);
+        const unsigned long long nodeMask = wave_ballot(cur >= 0);
         const int nBusy = __popcll(nowBusy), nNode = __popcll(nodeMask);
         const bool nodeStep = nNode > 0 && (nBusy - nNode) * 128 < leafPct * nBusy;
         bool done = false;
         if (nodeStep) {
             // ---- inner node of the top-level tree or of a mesh tree ------------------------------------
-            if (busy && cur >= 0) {
+            if (cur >= 0) {
                 tlim = __uint_as_float(((const uint32_t*)&L.best[owner])[1]);
                 int c[4];
                 uint32_t tested;
@@ -485,7 +484,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
             }
         } else {
             // ---- leaf step: mesh triangles dealt out over all 64 lanes (see trace_wave_steal), then top-level leaves
-            const bool atLeaf = busy && cur < 0;
+            const bool atLeaf = (uint32_t)cur > (uint32_t)kIdle;   // negative, but not kIdle
             const bool triLeaf = atLeaf && inMesh;
             const uint32_t leaf = (uint32_t)(~cur);
             const int left = (int)(leaf & 15u) + 1;
@@ -557,7 +556,7 @@ __device__ __forceinline__ TraceResult trace_wave_steal_inst(const SceneView& sv
             }
         }
         if (done) {
-            busy = false;
+            cur = kIdle;
             sp = 0; sb = 0;
             sentPos = -1;
             if constexpr (COUNT) { atomicAdd(&L.cnt[0][owner], wb); atomicAdd(&L.cnt[1][owner], wt); wb = 0; wt = 0; }
