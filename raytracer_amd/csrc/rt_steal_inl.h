@@ -31,7 +31,7 @@ namespace rt {
 #ifndef RT_STEAL_STACK
 #define RT_STEAL_STACK 14
 #endif
-constexpr int kStealStack = RT_STEAL_STACK;   // LDS stack entries per lane; with 14 the block is 5 KB: 7 waves per SIMD use 140 of a CU's 160 KB
+constexpr int kStealStack = RT_STEAL_STACK;   // LDS stack entries per lane; with 14 the block is 5 KB: 8 waves per SIMD use all of a CU's 160 KB
 
 template <bool COUNT>
 struct StealCounters {

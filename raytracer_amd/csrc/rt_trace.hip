@@ -12,6 +12,11 @@
 #include "rt_steal_inl.h"
 #include "rt_trace_inl.h"
 
+// waves per SIMD of the one-mesh batch kernels (see RT_TRACE_WAVES in rt_integrator.hip; bounce rays 6420 -> 6540 Mrays/s)
+#ifndef RT_BATCH_WAVES
+#define RT_BATCH_WAVES 8
+#endif
+
 namespace rt {
 
 // Launch position -> ray index.  A wave's 64 positions are spread over 8 runs of 8 consecutive
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(64) void trace_closest_kernel(SceneView sv, const f
 
 // Single-mesh scenes: wave-cooperative traversal with work stealing (rt_steal_inl.h).
 template <bool COUNT>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void trace_closest_steal_kernel(SceneView sv, const float* __restrict__ ro,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_BATCH_WAVES))) void trace_closest_steal_kernel(SceneView sv, const float* __restrict__ ro,
                                                                  const float* __restrict__ rd, uint64_t n, uint64_t nb8,
                                                                  rtgpu_hit* __restrict__ out, uint32_t* __restrict__ counts)
 {
@@ -84,7 +89,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void tr
     }
 }
 
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(7))) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(RT_BATCH_WAVES))) void trace_any_steal_kernel(SceneView sv, const float* __restrict__ ro,
                                                              const float* __restrict__ rd, const float* __restrict__ tmax,
                                                              uint64_t n, uint64_t nb8, uint8_t* __restrict__ occ)
 {
