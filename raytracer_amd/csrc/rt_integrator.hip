@@ -46,6 +46,11 @@
 #include "rt_photon_inl.h"
 #include "rt_wave_inl.h"
 
+// the first pass fits six waves per SIMD without a spill (78 VGPRs: shade stage 11.9 -> 11.6 ms per 1080p frame; seven spill
+// nine registers, 11.7 ms); the later passes need 96 registers (six waves: 19 spills, 13.1 ms)
+#ifndef RT_SHADE_WAVES_FIRST
+#define RT_SHADE_WAVES_FIRST 6
+#endif
 #ifndef RT_SHADE_WAVES
 #define RT_SHADE_WAVES 5   // waves per SIMD of the shade kernels without glass / add / photon-map code
 #endif
@@ -399,10 +404,10 @@ struct ShadeArgs {
 };
 
 template <bool FIRST, bool RICH>
-// five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took 98-111 of its own
-// accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and lose, and so does
-// five for the RICH variants)
-__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : RT_SHADE_WAVES, RICH ? 4 : RT_SHADE_WAVES))) void shade_kernel(ShadeArgs)
+// later passes, five waves per SIMD: the register allocator meets 96 VGPRs without spilling a vector register (it took
+// 98-111 of its own accord, i.e. four waves), and the passes wait on loads, so the fifth wave pays (six or eight spill and
+// lose, and so does five for the RICH variants); the first pass: six (RT_SHADE_WAVES_FIRST)
+__global__ __launch_bounds__(kShadeBlock) __attribute__((amdgpu_waves_per_eu(RICH ? 4 : (FIRST ? RT_SHADE_WAVES_FIRST : RT_SHADE_WAVES), RICH ? 4 : (FIRST ? RT_SHADE_WAVES_FIRST : RT_SHADE_WAVES)))) void shade_kernel(ShadeArgs)
 {
     // The arguments are read where they are used, through the kernel-argument segment's address, instead of through the
     // parameter: as a parameter every field the kernel uses is loaded into scalar registers at its entry and stays there,
